@@ -1,0 +1,867 @@
+// nt_api.cpp -- host side of libntracer_hip.so: the C ABI declared in include/ntracer_hip.h.
+//
+// Mirrors, for the ray-cast path only, what the reference does in C++ above its scenes:
+//   ImageFormat/Channel validation      src/render.cpp:120-164, 187-209, 249-288
+//   renderer frame loop and protocol    src/render.cpp:853-923 (busy / lock / abort)
+//   box_scene / composite_scene state   src/tracer.hpp:83-123, 1710-1748
+// The per-pixel work itself is in nt_kernels.hip.  There is NO CPU fallback: without a HIP
+// device every render entry point fails with NT_E_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ntracer_hip.h"
+#include "nt_device.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? NT_E_NOMEM : NT_E_DEVICE, \
+                                          "%s failed: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap && p) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max<size_t>(bytes, 256);
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct ChanTable {
+    std::vector<NtChanDev> host;
+    NtChanDev *dev = nullptr;
+};
+
+// everything a scene keeps on one HIP device
+struct DeviceState {
+    int device = -1;
+    hipStream_t stream = nullptr;        // used by the host-buffer entry points
+    bool scene_uploaded = false;
+    DevBuf nodes, items, batch_recs, batch_mats, tri_recs, tri_mats, solid_recs, solid_types, solid_mats, materials, aabb;
+    DevBuf lights;                       // pl_pos | pl_color | gl_dir | gl_color
+    unsigned long long lights_version = 0;
+    DevBuf framebuffer, cams, probes, stats;
+    std::vector<std::unique_ptr<ChanTable>> chan_tables;
+};
+
+struct Format {                          // validated image_format (render.cpp:167-172)
+    int width = 0, height = 0, pitch = 0, bpp = 0, reversed = 0;
+    std::vector<NtChanDev> chans;
+};
+
+}  // namespace
+
+struct nt_scene {
+    bool composite = false;
+    int n = 0;
+    std::mutex mu;
+    int locked = 0;
+    bool busy = false;
+    float fov = 0.8f;                    // tracer.hpp:91,1731
+    std::vector<float> origin, axes;     // camera<Store>: origin[n], t_orientation[n][n] (camera.hpp:7-15)
+
+    // composite_scene (tracer.hpp:1713-1740)
+    int root = -1;
+    int depth = 0;
+    std::vector<NtNode> nodes;
+    std::vector<int32_t> items;
+    int rec_len = 0, rec_stride = 0;
+    std::vector<float> batch_recs, tri_recs, solid_recs, materials, aabb;
+    std::vector<int32_t> batch_mats, tri_mats, solid_types, solid_mats;
+    int n_batches = 0, n_triangles = 0, n_solids = 0, n_materials = 0;
+    bool all_opaque = true, any_reflective = false, has_scalar = false;
+    int shadows = 0, camera_light = 1, max_reflect_depth = 4, bg_axis = 1;
+    float ambient[3] = {0, 0, 0}, bg1[3] = {1, 1, 1}, bg2[3] = {0, 0, 0}, bg3[3] = {0, 1, 1};
+    std::vector<float> pl_pos, pl_color, gl_dir, gl_color;
+    unsigned long long lights_version = 1;
+
+    std::map<int, std::unique_ptr<DeviceState>> devs;
+    nt_stats last_stats{};
+    bool have_stats = false;
+    int stats_device = -1;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// formats: Channel.__new__ (render.cpp:120-164), im_set_channels (:192-209), ImageFormat.__new__
+// (:249-288), im_check_buffer_size (:187-190)
+// ---------------------------------------------------------------------------------------------
+int parse_format(const nt_image_format *f, Format &out) {
+    if (!f) return fail(NT_E_INVALID, "format is NULL");
+    if (f->nchannels < 0 || (f->nchannels > 0 && !f->channels)) return fail(NT_E_INVALID, "invalid channel list");
+    long bits = 0;
+    out.chans.clear();
+    for (int i = 0; i < f->nchannels; ++i) {
+        const nt_channel &c = f->channels[i];
+        if (c.tfloat) {
+            if (c.bit_size != 32) return fail(NT_E_INVALID, "if \"tfloat\" is true, \"bit_size\" can only be 32");
+        } else {
+            if (c.bit_size > NT_MAX_BITSIZE) return fail(NT_E_INVALID, "\"bit_size\" cannot be greater than %d (unless \"tfloat\" is true)", NT_MAX_BITSIZE);
+            if (c.bit_size < 1) return fail(NT_E_INVALID, "\"bit_size\" cannot be less than 1");
+        }
+        bits += c.bit_size;
+        NtChanDev d;
+        d.f_r = c.f_r; d.f_g = c.f_g; d.f_b = c.f_b; d.f_c = c.f_c;
+        d.bits = c.bit_size;
+        d.tfloat = c.tfloat ? 1u : 0u;
+        out.chans.push_back(d);
+    }
+    if (bits > NT_MAX_PIXELSIZE * 8) return fail(NT_E_INVALID, "Too many bytes per pixel. The maximum is %d.", NT_MAX_PIXELSIZE);
+    out.bpp = (int)((bits + 7) / 8);
+    if (f->width < 1 || f->height < 1) return fail(NT_E_INVALID, "width and height must be at least 1");
+    if (f->pitch < 0) return fail(NT_E_INVALID, "pitch cannot be negative");
+    out.width = f->width;
+    out.height = f->height;
+    out.reversed = f->reversed ? 1 : 0;
+    if (f->pitch) {
+        if (f->pitch < f->width * out.bpp) return fail(NT_E_INVALID, "\"pitch\" must be at least \"width\" times the size of one pixel in bytes");
+        out.pitch = f->pitch;
+    } else {
+        out.pitch = f->width * out.bpp;
+    }
+    return NT_OK;
+}
+
+struct Bands {
+    int rank = 0, world = 1, rows = NT_RENDER_CHUNK_SIZE, compact = 0;
+    int owned_rows = 0;
+};
+
+int parse_bands(const nt_render_opts *o, int height, Bands &b) {
+    if (o) {
+        b.world = o->band_world > 1 ? o->band_world : 1;
+        b.rank = b.world > 1 ? o->band_rank : 0;
+        b.rows = o->band_rows > 0 ? o->band_rows : NT_RENDER_CHUNK_SIZE;
+        b.compact = o->compact ? 1 : 0;
+        if (b.rank < 0 || b.rank >= b.world) return fail(NT_E_INVALID, "band_rank %d out of range for band_world %d", o->band_rank, b.world);
+    }
+    if (b.world == 1) {
+        b.owned_rows = height;
+    } else {
+        // rows of bands rank, rank+world, ... clipped to the image
+        int owned = 0;
+        const int nbands = (height + b.rows - 1) / b.rows;
+        for (int band = b.rank; band < nbands; band += b.world) owned += std::min(b.rows, height - band * b.rows);
+        b.owned_rows = owned;
+    }
+    return NT_OK;
+}
+
+size_t required_len(const Format &f, const Bands &b) {
+    return (size_t)f.pitch * (size_t)(b.compact ? b.owned_rows : f.height);
+}
+
+// ---------------------------------------------------------------------------------------------
+// devices
+// ---------------------------------------------------------------------------------------------
+int pick_device(const nt_render_opts *o, int explicit_dev, int &dev) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1)
+        return fail(NT_E_DEVICE, "no HIP device available (%s): the ray-cast path has no CPU fallback", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    dev = explicit_dev;
+    if (o && o->device >= 0) dev = o->device;
+    if (dev < 0) {
+        HIP_TRY(hipGetDevice(&dev));
+    }
+    if (dev >= count) return fail(NT_E_INVALID, "device %d does not exist (%d devices)", dev, count);
+    HIP_TRY(hipSetDevice(dev));
+    return NT_OK;
+}
+
+int device_state(nt_scene *s, int dev, DeviceState *&out) {
+    auto it = s->devs.find(dev);
+    if (it == s->devs.end()) {
+        auto ds = std::make_unique<DeviceState>();
+        ds->device = dev;
+        HIP_TRY(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
+        it = s->devs.emplace(dev, std::move(ds)).first;
+    }
+    out = it->second.get();
+    return NT_OK;
+}
+
+template <typename T>
+int upload(DevBuf &b, const std::vector<T> &v) {
+    if (int r = b.ensure(std::max<size_t>(v.size() * sizeof(T), 16))) return r;
+    if (!v.empty()) HIP_TRY(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return NT_OK;
+}
+
+int upload_scene(nt_scene *s, DeviceState *ds) {
+    if (!s->composite) return NT_OK;
+    if (!ds->scene_uploaded) {
+        if (int r = upload(ds->nodes, s->nodes)) return r;
+        if (int r = upload(ds->items, s->items)) return r;
+        if (int r = upload(ds->batch_recs, s->batch_recs)) return r;
+        if (int r = upload(ds->batch_mats, s->batch_mats)) return r;
+        if (int r = upload(ds->tri_recs, s->tri_recs)) return r;
+        if (int r = upload(ds->tri_mats, s->tri_mats)) return r;
+        if (int r = upload(ds->solid_recs, s->solid_recs)) return r;
+        if (int r = upload(ds->solid_types, s->solid_types)) return r;
+        if (int r = upload(ds->solid_mats, s->solid_mats)) return r;
+        if (int r = upload(ds->materials, s->materials)) return r;
+        if (int r = upload(ds->aabb, s->aabb)) return r;
+        ds->scene_uploaded = true;
+    }
+    if (ds->lights_version != s->lights_version) {
+        std::vector<float> all;
+        all.insert(all.end(), s->pl_pos.begin(), s->pl_pos.end());
+        all.insert(all.end(), s->pl_color.begin(), s->pl_color.end());
+        all.insert(all.end(), s->gl_dir.begin(), s->gl_dir.end());
+        all.insert(all.end(), s->gl_color.begin(), s->gl_color.end());
+        // a fresh allocation: launches already enqueued keep reading the old one
+        DevBuf fresh;
+        if (int r = upload(fresh, all)) return r;
+        // the previous buffer may still be in use by enqueued work: free it only after the device drains
+        if (ds->lights.p) { (void)hipDeviceSynchronize(); ds->lights.release(); }
+        ds->lights = fresh;
+        ds->lights_version = s->lights_version;
+    }
+    return NT_OK;
+}
+
+int chan_table(DeviceState *ds, const Format &f, const NtChanDev *&dev_ptr) {
+    for (auto &t : ds->chan_tables) {
+        if (t->host.size() == f.chans.size() &&
+            (f.chans.empty() || std::memcmp(t->host.data(), f.chans.data(), f.chans.size() * sizeof(NtChanDev)) == 0)) {
+            dev_ptr = t->dev;
+            return NT_OK;
+        }
+    }
+    auto t = std::make_unique<ChanTable>();
+    t->host = f.chans;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(f.chans.size() * sizeof(NtChanDev), 16)));
+    t->dev = (NtChanDev *)p;
+    if (!f.chans.empty()) HIP_TRY(hipMemcpy(p, f.chans.data(), f.chans.size() * sizeof(NtChanDev), hipMemcpyHostToDevice));
+    dev_ptr = t->dev;
+    ds->chan_tables.push_back(std::move(t));
+    return NT_OK;
+}
+
+// camera rows the ray source needs: origin, right, up, forward (camera.hpp:40-45)
+void pack_camera(int n, const float *origin, const float *axes, float *out) {
+    std::memcpy(out, origin, sizeof(float) * n);
+    std::memcpy(out + n, axes, sizeof(float) * n);            // right  = t_orientation[0]
+    std::memcpy(out + 2 * n, axes + n, sizeof(float) * n);    // up     = t_orientation[1]
+    std::memcpy(out + 3 * n, axes + 2 * n, sizeof(float) * n);// forward= t_orientation[2]
+}
+
+void fill_view(NtTarget &tg, const nt_scene *s, int w, int h) {
+    // flat_origin_ray_source::set_params (tracer.hpp:65-69)
+    tg.width = w;
+    tg.height = h;
+    tg.half_w = float(w) / float(2);
+    tg.half_h = float(h) / float(2);
+    tg.fovI = std::tan(s->fov / 2) / tg.half_w;
+}
+
+void fill_composite(const nt_scene *s, const DeviceState *ds, NtCompositeDev &c, bool stats) {
+    std::memset(&c, 0, sizeof(c));
+    c.nodes = (const NtNode *)ds->nodes.p;
+    c.items = (const int *)ds->items.p;
+    c.batch_recs = (const float *)ds->batch_recs.p;
+    c.batch_mats = (const int *)ds->batch_mats.p;
+    c.tri_recs = (const float *)ds->tri_recs.p;
+    c.tri_mats = (const int *)ds->tri_mats.p;
+    c.solid_recs = (const float *)ds->solid_recs.p;
+    c.solid_types = (const int *)ds->solid_types.p;
+    c.solid_mats = (const int *)ds->solid_mats.p;
+    c.materials = (const float *)ds->materials.p;
+    c.aabb = (const float *)ds->aabb.p;
+    c.rec_stride = s->rec_stride;
+    c.root = s->root;
+    c.stack_depth = std::max(s->depth + 1, 2);
+    c.shadows = s->shadows;
+    c.camera_light = s->camera_light;
+    c.max_reflect_depth = s->max_reflect_depth;
+    c.bg_axis = s->bg_axis;
+    for (int k = 0; k < 3; ++k) { c.ambient[k] = s->ambient[k]; c.bg1[k] = s->bg1[k]; c.bg2[k] = s->bg2[k]; c.bg3[k] = s->bg3[k]; }
+    const float *lp = (const float *)ds->lights.p;
+    c.n_point_lights = (int)(s->pl_color.size() / 3);
+    c.n_global_lights = (int)(s->gl_color.size() / 3);
+    c.pl_pos = lp;
+    c.pl_color = lp + s->pl_pos.size();
+    c.gl_dir = c.pl_color + s->pl_color.size();
+    c.gl_color = c.gl_dir + s->gl_dir.size();
+    c.all_opaque = s->all_opaque;
+    c.any_reflective = s->any_reflective;
+    c.has_scalar_prims = s->has_scalar;
+    c.stats = stats ? (unsigned long long *)ds->stats.p : nullptr;
+}
+
+int check_renderable(const nt_scene *s) {
+    if (s->composite) {
+        if (s->n > NT_MAX_FIXED_DIM) return fail(NT_E_UNSUPPORTED, "composite scenes are implemented for dimensions 3..%d (got %d)", NT_MAX_FIXED_DIM, s->n);
+        if (!s->all_opaque) return fail(NT_E_UNSUPPORTED, "transparent materials (opacity < 1) are not implemented on the GPU path yet");
+        if (s->max_reflect_depth > NT_DEV_MAX_REFLECT && s->any_reflective)
+            return fail(NT_E_UNSUPPORTED, "max_reflect_depth > %d is not supported", NT_DEV_MAX_REFLECT);
+    }
+    return NT_OK;
+}
+
+// the renderer protocol of obj_BlockingRenderer_render (render.cpp:878-904): refuse re-entry, lock the scene
+struct RenderGuard {
+    nt_scene *s;
+    bool held = false;
+    explicit RenderGuard(nt_scene *sc) : s(sc) {}
+    int acquire() {
+        std::lock_guard<std::mutex> g(s->mu);
+        if (s->busy) return fail(NT_E_BUSY, "the renderer is already running");
+        s->busy = true;
+        ++s->locked;
+        held = true;
+        return NT_OK;
+    }
+    ~RenderGuard() {
+        if (held) {
+            std::lock_guard<std::mutex> g(s->mu);
+            s->busy = false;
+            --s->locked;
+        }
+    }
+};
+
+struct FrameJob {
+    const Format *fmt;
+    Bands bands;
+    void *dest_dev;
+    size_t frame_stride;
+    int nframes;
+    const float *cam_buf;     // device [nframes][4][n] or nullptr
+    hipStream_t stream;
+    bool stats;
+    int row_begin, row_count; // owned-row slab
+    // probe mode
+    float *colors_out = nullptr;
+    const int *xs = nullptr, *ys = nullptr;
+    int probe_count = 0;
+    int view_w = 0, view_h = 0;
+};
+
+int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
+    NtTarget tg;
+    std::memset(&tg, 0, sizeof(tg));
+    if (job.colors_out) {
+        fill_view(tg, s, job.view_w, job.view_h);
+        tg.colors_out = job.colors_out;
+        tg.probe_xs = job.xs;
+        tg.probe_ys = job.ys;
+        tg.probe_count = job.probe_count;
+        tg.band_world = 1;
+        tg.band_rows = NT_RENDER_CHUNK_SIZE;
+    } else {
+        const Format &f = *job.fmt;
+        fill_view(tg, s, f.width, f.height);
+        tg.dest = (uint8_t *)job.dest_dev;
+        tg.frame_stride = (long long)job.frame_stride;
+        const NtChanDev *chans = nullptr;
+        if (int r = chan_table(ds, f, chans)) return r;
+        tg.chans = chans;
+        tg.nchannels = (int)f.chans.size();
+        tg.bpp = f.bpp;
+        tg.reversed = f.reversed;
+        tg.pitch = f.pitch;
+        tg.band_rank = job.bands.rank;
+        tg.band_world = job.bands.world;
+        tg.band_rows = job.bands.rows;
+        tg.compact = job.bands.compact;
+        tg.row_begin = job.row_begin;
+        tg.row_count = job.row_count;
+        tg.aligned4 = ((uintptr_t)job.dest_dev % 4 == 0) && (f.pitch % 4 == 0) && (job.frame_stride % 4 == 0);
+        if (tg.row_count <= 0 || f.bpp == 0) return NT_OK;      // nothing to draw
+    }
+    NtCamera cam;
+    cam.buf = job.cam_buf;
+    cam.n = s->n;
+    if (!job.cam_buf) pack_camera(s->n, s->origin.data(), s->axes.data(), cam.inl);
+    NtLaunchInfo li;
+    li.n = s->n;
+    li.nframes = job.nframes;
+    li.stream = job.stream;
+    int r;
+    if (s->composite) {
+        NtCompositeDev c;
+        fill_composite(s, ds, c, job.stats);
+        if (c.root < 0) c.root = -1;
+        r = nt_launch_composite(li, cam, c, tg);
+    } else {
+        r = nt_launch_box(li, cam, tg);
+    }
+    if (r) return fail(r == -2 ? NT_E_UNSUPPORTED : NT_E_DEVICE, "%s", nt_launch_error());
+    return NT_OK;
+}
+
+int prepare_stats(DeviceState *ds, hipStream_t st, bool on) {
+    if (!on) return NT_OK;
+    if (int r = ds->stats.ensure(8 * sizeof(unsigned long long))) return r;
+    HIP_TRY(hipMemsetAsync(ds->stats.p, 0, 8 * sizeof(unsigned long long), st));
+    return NT_OK;
+}
+
+int validate_desc(const nt_scene_desc *d) {
+    if (!d) return fail(NT_E_INVALID, "scene description is NULL");
+    const int n = d->dimension;
+    if (n < 3 || n > NT_MAX_DIM) return fail(NT_E_INVALID, "dimension must be between 3 and %d", NT_MAX_DIM);
+    if (d->n_nodes < 0 || d->n_items < 0 || d->n_batches < 0 || d->n_triangles < 0 || d->n_solids < 0 || d->n_materials < 0)
+        return fail(NT_E_INVALID, "negative count in scene description");
+    if (d->root < -1 || d->root >= d->n_nodes) return fail(NT_E_INVALID, "root index out of range");
+    if (!d->aabb_start || !d->aabb_end) return fail(NT_E_INVALID, "scene boundary is required");
+    if (d->n_nodes && (!d->node_axis || !d->node_split || !d->node_left || !d->node_right)) return fail(NT_E_INVALID, "node arrays are NULL");
+    if (d->n_items && !d->items) return fail(NT_E_INVALID, "items array is NULL");
+    if (d->n_batches && (!d->batch_recs || !d->batch_mats)) return fail(NT_E_INVALID, "batch arrays are NULL");
+    if (d->n_triangles && (!d->tri_recs || !d->tri_mats)) return fail(NT_E_INVALID, "triangle arrays are NULL");
+    if (d->n_solids && (!d->solid_recs || !d->solid_types || !d->solid_mats)) return fail(NT_E_INVALID, "solid arrays are NULL");
+    if ((d->n_batches || d->n_triangles || d->n_solids) && (!d->materials || d->n_materials < 1)) return fail(NT_E_INVALID, "materials are required");
+    for (int i = 0; i < d->n_nodes; ++i) {
+        const int ax = d->node_axis[i];
+        if (ax >= n || ax < -1) return fail(NT_E_INVALID, "node %d: axis %d out of range", i, ax);
+        if (ax < 0) {
+            const long st = d->node_left[i], cnt = d->node_right[i];
+            if (st < 0 || cnt < 1 || st + cnt > d->n_items) return fail(NT_E_INVALID, "leaf %d: item range out of bounds", i);
+        } else {
+            const int l = d->node_left[i], r = d->node_right[i];
+            if (l < -1 || l >= d->n_nodes || r < -1 || r >= d->n_nodes) return fail(NT_E_INVALID, "branch %d: child index out of range", i);
+            if (l < 0 && r < 0) return fail(NT_E_INVALID, "branch %d: both children are empty", i);
+        }
+    }
+    for (int i = 0; i < d->n_items; ++i) {
+        const int it = d->items[i];
+        const int kind = it & 3, idx = it >> 2;
+        const int lim = kind == NT_KIND_BATCH ? d->n_batches : kind == NT_KIND_TRIANGLE ? d->n_triangles : kind == NT_KIND_SOLID ? d->n_solids : -1;
+        if (it < 0 || idx >= lim) return fail(NT_E_INVALID, "item %d: primitive reference out of range", i);
+    }
+    auto check_mats = [&](const int32_t *m, long cnt) {
+        for (long i = 0; i < cnt; ++i) if (m[i] < 0 || m[i] >= d->n_materials) return false;
+        return true;
+    };
+    if (!check_mats(d->batch_mats, (long)d->n_batches * NT_BATCH_SIZE) || !check_mats(d->tri_mats, d->n_triangles) || !check_mats(d->solid_mats, d->n_solids))
+        return fail(NT_E_INVALID, "material index out of range");
+    for (int i = 0; i < d->n_solids; ++i)
+        if (d->solid_types[i] != NT_SOLID_CUBE && d->solid_types[i] != NT_SOLID_SPHERE) return fail(NT_E_INVALID, "solid %d: unknown type", i);
+    return NT_OK;
+}
+
+// depth of the tree + cycle check (every node reachable at most once)
+int tree_depth(const nt_scene_desc *d, int &depth_out) {
+    depth_out = 0;
+    if (d->root < 0) return NT_OK;
+    std::vector<char> seen((size_t)d->n_nodes, 0);
+    std::vector<std::pair<int, int>> stack;
+    stack.emplace_back(d->root, 1);
+    while (!stack.empty()) {
+        auto [node, dep] = stack.back();
+        stack.pop_back();
+        if (seen[node]) return fail(NT_E_INVALID, "node %d is referenced more than once (the k-d tree must be a tree)", node);
+        seen[node] = 1;
+        depth_out = std::max(depth_out, dep);
+        if (d->node_axis[node] >= 0) {
+            if (d->node_left[node] >= 0) stack.emplace_back(d->node_left[node], dep + 1);
+            if (d->node_right[node] >= 0) stack.emplace_back(d->node_right[node], dep + 1);
+        }
+    }
+    return NT_OK;
+}
+
+void pad_records(const float *src, long count, int rec_len, int stride, std::vector<float> &out) {
+    out.assign((size_t)count * stride, 0.0f);
+    for (long i = 0; i < count; ++i) std::memcpy(out.data() + (size_t)i * stride, src + (size_t)i * rec_len, sizeof(float) * rec_len);
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char *nt_version(void) { return "ntracer_hip 0.1 (gfx950)"; }
+
+const char *nt_last_error(void) { return g_error.c_str(); }
+
+int nt_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+nt_scene_t *nt_box_scene_create(int dimension) {
+    if (dimension < 3 || dimension > NT_MAX_DIM) {
+        fail(NT_E_INVALID, "dimension must be between 3 and %d", NT_MAX_DIM);
+        return nullptr;
+    }
+    nt_scene *s = new (std::nothrow) nt_scene();
+    if (!s) { fail(NT_E_NOMEM, "out of memory"); return nullptr; }
+    s->composite = false;
+    s->n = dimension;
+    s->origin.assign(dimension, 0.0f);                 // camera(d): origin 0, identity axes (camera.hpp:11)
+    s->axes.assign((size_t)dimension * dimension, 0.0f);
+    for (int i = 0; i < dimension; ++i) s->axes[(size_t)i * dimension + i] = 1.0f;
+    return s;
+}
+
+nt_scene_t *nt_composite_scene_create(const nt_scene_desc *d) {
+    if (validate_desc(d)) return nullptr;
+    int depth = 0;
+    if (tree_depth(d, depth)) return nullptr;
+    nt_scene *s = new (std::nothrow) nt_scene();
+    if (!s) { fail(NT_E_NOMEM, "out of memory"); return nullptr; }
+    const int n = d->dimension;
+    s->composite = true;
+    s->n = n;
+    s->origin.assign(n, 0.0f);
+    s->axes.assign((size_t)n * n, 0.0f);
+    for (int i = 0; i < n; ++i) s->axes[(size_t)i * n + i] = 1.0f;
+    s->root = d->root;
+    s->depth = depth;
+    s->nodes.resize((size_t)d->n_nodes);
+    for (int i = 0; i < d->n_nodes; ++i) {
+        s->nodes[i].split = d->node_split[i];
+        s->nodes[i].axis = d->node_axis[i];
+        s->nodes[i].left = d->node_left[i];
+        s->nodes[i].right = d->node_right[i];
+    }
+    s->items.assign(d->items, d->items + d->n_items);
+    s->rec_len = n * n + n + 1;
+    s->rec_stride = (s->rec_len + 3) / 4 * 4;
+    s->n_batches = d->n_batches;
+    s->n_triangles = d->n_triangles;
+    s->n_solids = d->n_solids;
+    s->n_materials = d->n_materials;
+    pad_records(d->batch_recs, (long)d->n_batches * NT_BATCH_SIZE, s->rec_len, s->rec_stride, s->batch_recs);
+    pad_records(d->tri_recs, d->n_triangles, s->rec_len, s->rec_stride, s->tri_recs);
+    s->batch_mats.assign(d->batch_mats, d->batch_mats + (size_t)d->n_batches * NT_BATCH_SIZE);
+    s->tri_mats.assign(d->tri_mats, d->tri_mats + d->n_triangles);
+    s->solid_recs.assign(d->solid_recs, d->solid_recs + (size_t)d->n_solids * (2 * n * n + n));
+    s->solid_types.assign(d->solid_types, d->solid_types + d->n_solids);
+    s->solid_mats.assign(d->solid_mats, d->solid_mats + d->n_solids);
+    s->materials.resize((size_t)d->n_materials * 10);
+    for (int i = 0; i < d->n_materials; ++i) {
+        const nt_material &m = d->materials[i];
+        float *o = s->materials.data() + (size_t)i * 10;
+        o[0] = m.color[0]; o[1] = m.color[1]; o[2] = m.color[2];
+        o[3] = m.specular[0]; o[4] = m.specular[1]; o[5] = m.specular[2];
+        o[6] = m.opacity; o[7] = m.reflectivity; o[8] = m.specular_intensity; o[9] = m.specular_exp;
+        if (!(m.opacity >= 1.0f)) s->all_opaque = false;       // primitive::opaque (tracer.hpp:187)
+        if (m.reflectivity != 0.0f) s->any_reflective = true;
+    }
+    s->has_scalar = false;
+    for (int i = 0; i < d->n_items; ++i) if ((d->items[i] & 3) != NT_KIND_BATCH) s->has_scalar = true;
+    s->aabb.assign(d->aabb_start, d->aabb_start + n);
+    s->aabb.insert(s->aabb.end(), d->aabb_end, d->aabb_end + n);
+    return s;
+}
+
+void nt_scene_destroy(nt_scene_t *s) {
+    if (!s) return;
+    for (auto &kv : s->devs) {
+        DeviceState *ds = kv.second.get();
+        if (hipSetDevice(ds->device) != hipSuccess) continue;
+        (void)hipDeviceSynchronize();
+        for (DevBuf *b : {&ds->nodes, &ds->items, &ds->batch_recs, &ds->batch_mats, &ds->tri_recs, &ds->tri_mats, &ds->solid_recs,
+                          &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams,
+                          &ds->probes, &ds->stats})
+            b->release();
+        for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
+        if (ds->stream) (void)hipStreamDestroy(ds->stream);
+    }
+    delete s;
+}
+
+int nt_scene_dimension(const nt_scene_t *s) { return s ? s->n : fail(NT_E_INVALID, "scene is NULL"); }
+int nt_scene_is_composite(const nt_scene_t *s) { return s ? (s->composite ? 1 : 0) : fail(NT_E_INVALID, "scene is NULL"); }
+
+int nt_scene_set_camera(nt_scene_t *s, const float *origin, const float *axes) {
+    if (!s || !origin || !axes) return fail(NT_E_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->locked) return fail(NT_E_LOCKED, "the scene is locked for reading");
+    s->origin.assign(origin, origin + s->n);
+    s->axes.assign(axes, axes + (size_t)s->n * s->n);
+    return NT_OK;
+}
+
+int nt_scene_get_camera(const nt_scene_t *s, float *origin, float *axes) {
+    if (!s || !origin || !axes) return fail(NT_E_INVALID, "NULL argument");
+    std::memcpy(origin, s->origin.data(), sizeof(float) * s->n);
+    std::memcpy(axes, s->axes.data(), sizeof(float) * s->n * s->n);
+    return NT_OK;
+}
+
+int nt_scene_set_fov(nt_scene_t *s, float fov) {
+    if (!s) return fail(NT_E_INVALID, "scene is NULL");
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->locked) return fail(NT_E_LOCKED, "the scene is locked for reading");
+    s->fov = fov;
+    return NT_OK;
+}
+
+float nt_scene_get_fov(const nt_scene_t *s) { return s ? s->fov : 0.0f; }
+
+int nt_scene_set_params(nt_scene_t *s, const nt_scene_params *p) {
+    if (!s || !p) return fail(NT_E_INVALID, "NULL argument");
+    if (!s->composite) return fail(NT_E_INVALID, "BoxScene has no lighting parameters");
+    if (p->bg_gradient_axis < 0 || p->bg_gradient_axis >= s->n) return fail(NT_E_INVALID, "bg_gradient_axis out of range");
+    if (p->n_point_lights < 0 || p->n_global_lights < 0) return fail(NT_E_INVALID, "negative light count");
+    if ((p->n_point_lights && (!p->point_light_pos || !p->point_light_color)) || (p->n_global_lights && (!p->global_light_dir || !p->global_light_color)))
+        return fail(NT_E_INVALID, "light arrays are NULL");
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->locked) return fail(NT_E_LOCKED, "the scene is locked for reading");
+    s->shadows = p->shadows ? 1 : 0;
+    s->camera_light = p->camera_light ? 1 : 0;
+    s->max_reflect_depth = p->max_reflect_depth;
+    s->bg_axis = p->bg_gradient_axis;
+    for (int k = 0; k < 3; ++k) { s->ambient[k] = p->ambient[k]; s->bg1[k] = p->bg1[k]; s->bg2[k] = p->bg2[k]; s->bg3[k] = p->bg3[k]; }
+    const int n = s->n;
+    s->pl_pos.assign(p->point_light_pos, p->point_light_pos + (size_t)p->n_point_lights * n);
+    s->pl_color.assign(p->point_light_color, p->point_light_color + (size_t)p->n_point_lights * 3);
+    s->gl_dir.assign(p->global_light_dir, p->global_light_dir + (size_t)p->n_global_lights * n);
+    s->gl_color.assign(p->global_light_color, p->global_light_color + (size_t)p->n_global_lights * 3);
+    ++s->lights_version;
+    return NT_OK;
+}
+
+int nt_scene_lock(nt_scene_t *s) {
+    if (!s) return fail(NT_E_INVALID, "scene is NULL");
+    std::lock_guard<std::mutex> g(s->mu);
+    ++s->locked;
+    return NT_OK;
+}
+
+int nt_scene_unlock(nt_scene_t *s) {
+    if (!s) return fail(NT_E_INVALID, "scene is NULL");
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->locked <= 0) return fail(NT_E_INVALID, "the scene is not locked");
+    --s->locked;
+    return NT_OK;
+}
+
+int nt_scene_locked(const nt_scene_t *s) { return s ? (s->locked > 0 ? 1 : 0) : fail(NT_E_INVALID, "scene is NULL"); }
+
+int nt_format_bytes_per_pixel(const nt_image_format *fmt) {
+    Format f;
+    if (int r = parse_format(fmt, f)) return r;
+    return f.bpp;
+}
+
+int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format *fmt, const nt_render_opts *opts, volatile int *abort_flag) {
+    if (!s || !dest) return fail(NT_E_INVALID, "NULL argument");
+    Format f;
+    if (int r = parse_format(fmt, f)) return r;
+    Bands b;
+    if (int r = parse_bands(opts, f.height, b)) return r;
+    const size_t need = required_len(f, b);
+    if (dest_len < need) return fail(NT_E_INVALID, "the buffer is too small for an image with the given dimensions");
+    if (int r = check_renderable(s)) return r;
+    RenderGuard guard(s);
+    if (int r = guard.acquire()) return r;
+    int dev;
+    if (int r = pick_device(opts, -1, dev)) return r;
+    DeviceState *ds;
+    if (int r = device_state(s, dev, ds)) return r;
+    if (int r = upload_scene(s, ds)) return r;
+    if (int r = ds->framebuffer.ensure(std::max<size_t>(need, 16))) return r;
+    const bool stats = opts && opts->collect_stats;
+    if (int r = prepare_stats(ds, ds->stream, stats)) return r;
+    // pitch padding bytes are not written by the kernels: carry the caller's bytes through
+    if (f.pitch != f.width * f.bpp || (b.world > 1 && !b.compact)) HIP_TRY(hipMemcpyAsync(ds->framebuffer.p, dest, need, hipMemcpyHostToDevice, ds->stream));
+
+    FrameJob job{};
+    job.fmt = &f;
+    job.bands = b;
+    job.dest_dev = ds->framebuffer.p;
+    job.frame_stride = 0;
+    job.nframes = 1;
+    job.cam_buf = nullptr;
+    job.stream = ds->stream;
+    job.stats = stats;
+    // abort is polled between slab launches (the reference polls per pixel, render.cpp:412)
+    const int slab = abort_flag ? std::max(64, (b.owned_rows + 7) / 8 / 16 * 16) : b.owned_rows;
+    bool aborted = false;
+    for (int r0 = 0; r0 < b.owned_rows; r0 += slab) {
+        if (abort_flag && *abort_flag) { aborted = true; break; }
+        job.row_begin = r0;
+        job.row_count = std::min(slab, b.owned_rows - r0);
+        if (int r = enqueue(s, ds, job)) { (void)hipStreamSynchronize(ds->stream); return r; }
+        if (abort_flag) HIP_TRY(hipStreamSynchronize(ds->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(dest, ds->framebuffer.p, need, hipMemcpyDeviceToHost, ds->stream));
+    HIP_TRY(hipStreamSynchronize(ds->stream));
+    if (stats) {
+        unsigned long long v[8];
+        HIP_TRY(hipMemcpy(v, ds->stats.p, sizeof(v), hipMemcpyDeviceToHost));
+        s->last_stats.rays = v[0]; s->last_stats.shadow_rays = v[1]; s->last_stats.branches = v[2]; s->last_stats.leaves = v[3];
+        s->last_stats.simplex_tests = v[4]; s->last_stats.solid_tests = v[5]; s->last_stats.hits = v[6]; s->last_stats.aabb_enter = v[7];
+        s->have_stats = true;
+    }
+    if (abort_flag && *abort_flag) aborted = true;
+    return aborted ? NT_ABORTED : NT_OK;
+}
+
+int nt_render_device(nt_scene_t *s, void *dest_dev, size_t dest_len, const nt_image_format *fmt, const nt_render_opts *opts, void *hip_stream) {
+    if (!s || !dest_dev) return fail(NT_E_INVALID, "NULL argument");
+    Format f;
+    if (int r = parse_format(fmt, f)) return r;
+    Bands b;
+    if (int r = parse_bands(opts, f.height, b)) return r;
+    if (dest_len < required_len(f, b)) return fail(NT_E_INVALID, "the buffer is too small for an image with the given dimensions");
+    if (int r = check_renderable(s)) return r;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->busy) return fail(NT_E_BUSY, "the renderer is already running");
+    int dev;
+    if (int r = pick_device(opts, -1, dev)) return r;
+    DeviceState *ds;
+    if (int r = device_state(s, dev, ds)) return r;
+    if (int r = upload_scene(s, ds)) return r;
+    const bool stats = opts && opts->collect_stats;
+    if (int r = prepare_stats(ds, (hipStream_t)hip_stream, stats)) return r;
+    if (stats) { s->have_stats = false; s->stats_device = dev; }
+    FrameJob job{};
+    job.fmt = &f;
+    job.bands = b;
+    job.dest_dev = dest_dev;
+    job.nframes = 1;
+    job.stream = (hipStream_t)hip_stream;
+    job.stats = stats;
+    job.row_begin = 0;
+    job.row_count = b.owned_rows;
+    return enqueue(s, ds, job);
+}
+
+int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, int nframes, const float *origins, const float *axes,
+                            const nt_image_format *fmt, const nt_render_opts *opts, void *hip_stream) {
+    if (!s || !dest_dev || !origins || !axes) return fail(NT_E_INVALID, "NULL argument");
+    if (nframes < 1 || nframes > 65535) return fail(NT_E_INVALID, "nframes must be between 1 and 65535");
+    Format f;
+    if (int r = parse_format(fmt, f)) return r;
+    Bands b;
+    if (int r = parse_bands(opts, f.height, b)) return r;
+    if (frame_stride < required_len(f, b)) return fail(NT_E_INVALID, "frame_stride is smaller than one frame");
+    if (int r = check_renderable(s)) return r;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->busy) return fail(NT_E_BUSY, "the renderer is already running");
+    int dev;
+    if (int r = pick_device(opts, -1, dev)) return r;
+    DeviceState *ds;
+    if (int r = device_state(s, dev, ds)) return r;
+    if (int r = upload_scene(s, ds)) return r;
+    const int n = s->n;
+    std::vector<float> packed((size_t)nframes * 4 * n);
+    for (int fidx = 0; fidx < nframes; ++fidx)
+        pack_camera(n, origins + (size_t)fidx * n, axes + (size_t)fidx * n * n, packed.data() + (size_t)fidx * 4 * n);
+    // a camera table that earlier launches may still read must not be overwritten: grow-only buffer,
+    // refilled only after the stream that used it has drained (same-stream ordering)
+    if (int r = ds->cams.ensure(packed.size() * sizeof(float))) return r;
+    HIP_TRY(hipMemcpyAsync(ds->cams.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    const bool stats = opts && opts->collect_stats;
+    if (int r = prepare_stats(ds, (hipStream_t)hip_stream, stats)) return r;
+    if (stats) { s->have_stats = false; s->stats_device = dev; }
+    FrameJob job{};
+    job.fmt = &f;
+    job.bands = b;
+    job.dest_dev = dest_dev;
+    job.frame_stride = frame_stride;
+    job.nframes = nframes;
+    job.cam_buf = (const float *)ds->cams.p;
+    job.stream = (hipStream_t)hip_stream;
+    job.stats = stats;
+    job.row_begin = 0;
+    job.row_count = b.owned_rows;
+    return enqueue(s, ds, job);
+}
+
+int nt_colors_at(nt_scene_t *s, int width, int height, int count, const int32_t *xs, const int32_t *ys, float *rgb, int device) {
+    if (!s || (count > 0 && (!xs || !ys || !rgb))) return fail(NT_E_INVALID, "NULL argument");
+    if (width < 1 || height < 1 || count < 0) return fail(NT_E_INVALID, "invalid view size or count");
+    if (count == 0) return NT_OK;
+    if (int r = check_renderable(s)) return r;
+    RenderGuard guard(s);   // Scene.calculate_color locks the scene for the call (render.cpp:599-603)
+    if (int r = guard.acquire()) return r;
+    int dev;
+    if (int r = pick_device(nullptr, device, dev)) return r;
+    DeviceState *ds;
+    if (int r = device_state(s, dev, ds)) return r;
+    if (int r = upload_scene(s, ds)) return r;
+    const size_t ibytes = (size_t)count * sizeof(int32_t);
+    const size_t cbytes = (size_t)count * 3 * sizeof(float);
+    if (int r = ds->probes.ensure(2 * ibytes + cbytes)) return r;
+    char *base = (char *)ds->probes.p;
+    HIP_TRY(hipMemcpyAsync(base, xs, ibytes, hipMemcpyHostToDevice, ds->stream));
+    HIP_TRY(hipMemcpyAsync(base + ibytes, ys, ibytes, hipMemcpyHostToDevice, ds->stream));
+    FrameJob job{};
+    job.nframes = 1;
+    job.stream = ds->stream;
+    job.colors_out = (float *)(base + 2 * ibytes);
+    job.xs = (const int *)base;
+    job.ys = (const int *)(base + ibytes);
+    job.probe_count = count;
+    job.view_w = width;
+    job.view_h = height;
+    if (int r = enqueue(s, ds, job)) { (void)hipStreamSynchronize(ds->stream); return r; }
+    HIP_TRY(hipMemcpyAsync(rgb, base + 2 * ibytes, cbytes, hipMemcpyDeviceToHost, ds->stream));
+    HIP_TRY(hipStreamSynchronize(ds->stream));
+    return NT_OK;
+}
+
+int nt_calculate_color(nt_scene_t *s, int x, int y, int width, int height, float rgb[3]) {
+    const int32_t xs = x, ys = y;
+    return nt_colors_at(s, width, height, 1, &xs, &ys, rgb, -1);
+}
+
+int nt_scene_last_stats(const nt_scene_t *cs, nt_stats *out) {
+    nt_scene *s = const_cast<nt_scene *>(cs);
+    if (!s || !out) return fail(NT_E_INVALID, "NULL argument");
+    if (!s->have_stats) {
+        if (s->stats_device < 0) return fail(NT_E_INVALID, "no render with collect_stats has run on this scene");
+        auto it = s->devs.find(s->stats_device);
+        if (it == s->devs.end() || !it->second->stats.p) return fail(NT_E_INVALID, "no statistics available");
+        HIP_TRY(hipSetDevice(s->stats_device));
+        HIP_TRY(hipDeviceSynchronize());
+        unsigned long long v[8];
+        HIP_TRY(hipMemcpy(v, it->second->stats.p, sizeof(v), hipMemcpyDeviceToHost));
+        s->last_stats.rays = v[0]; s->last_stats.shadow_rays = v[1]; s->last_stats.branches = v[2]; s->last_stats.leaves = v[3];
+        s->last_stats.simplex_tests = v[4]; s->last_stats.solid_tests = v[5]; s->last_stats.hits = v[6]; s->last_stats.aabb_enter = v[7];
+        s->have_stats = true;
+    }
+    *out = s->last_stats;
+    return NT_OK;
+}
+
+}  // extern "C"

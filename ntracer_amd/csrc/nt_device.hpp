@@ -1,0 +1,100 @@
+// nt_device.hpp -- structures shared by the host API (nt_api.cpp) and the HIP kernels
+// (nt_kernels.hip).  gfx950 only.
+#pragma once
+#include <stdint.h>
+
+#define NT_DEV_MAX_DIM 64
+#define NT_DEV_MAX_FIXED 8
+#define NT_DEV_BATCH 4
+#define NT_DEV_MAX_REFLECT 16
+
+// reference: ROUNDING_FUZZ = numeric_limits<float>::epsilon()*10 (src/tracer.hpp:25)
+#define NT_FUZZ (1.1920928955078125e-07f * 10.0f)
+// reference: LIGHT_THRESHOLD (src/tracer.hpp:31)
+#define NT_LIGHT_THRESHOLD (1.0f / 512.0f)
+
+struct NtChanDev {          // render.cpp:95-99 channel
+    float f_r, f_g, f_b, f_c;
+    uint32_t bits;
+    uint32_t tfloat;
+};
+
+// Where the pixels of one launch go.  Rows are dealt to ranks in bands of `band_rows`
+// (RENDER_CHUNK_SIZE, render.cpp:43): owned row r -> image row
+//   y = ((r / band_rows) * band_world + band_rank) * band_rows + r % band_rows.
+struct NtTarget {
+    uint8_t *dest;
+    long long frame_stride;   // bytes between frames (blockIdx.z)
+    const NtChanDev *chans;
+    int nchannels, bpp, reversed, pitch;
+    int width, height;        // view size: set_view_size(w,h) (tracer.hpp:65-69)
+    float half_w, half_h, fovI;
+    int band_rank, band_world, band_rows, compact;
+    int row_begin, row_count; // owned-row range rendered by this launch
+    int aligned4;             // dest, pitch and frame_stride are 4-byte aligned
+    // probe mode (nt_colors_at / nt_calculate_color): fp32 colours of listed pixels
+    float *colors_out;
+    const int *probe_xs, *probe_ys;
+    int probe_count;
+};
+
+// Camera rows used by the ray source (camera.hpp:40-45): origin, right, up, forward.
+// Either inline in the kernel arguments (single frame) or from a device buffer
+// [frame][4][n] (multi-frame launches).
+struct NtCamera {
+    const float *buf;         // nullptr => use `inl`
+    int n;
+    float inl[4 * NT_DEV_MAX_DIM];
+};
+struct NtCameraFixed {        // N <= 8: 4*8 floats inline
+    const float *buf;
+    int n;
+    float inl[4 * NT_DEV_MAX_FIXED];
+};
+
+struct NtNode {               // 16-byte k-d node record
+    float split;
+    int axis;                 // -1: leaf
+    int left;                 // branch: child or -1; leaf: first item
+    int right;                // branch: child or -1; leaf: item count
+};
+
+struct NtCompositeDev {
+    const NtNode *nodes;
+    const int *items;
+    const float *batch_recs;  // [n_batches*4][rec_stride]
+    const int *batch_mats;
+    const float *tri_recs;    // [n_triangles][rec_stride]
+    const int *tri_mats;
+    const float *solid_recs;  // [n_solids][2*n*n+n]
+    const int *solid_types;
+    const int *solid_mats;
+    const float *materials;   // [n_materials][10]
+    const float *aabb;        // start[n], end[n]
+    int rec_stride;           // floats per simplex record, multiple of 4
+    int root;
+    int stack_depth;          // LDS stack entries per lane
+    int shadows, camera_light, max_reflect_depth, bg_axis;
+    float ambient[3], bg1[3], bg2[3], bg3[3];
+    int n_point_lights;
+    const float *pl_pos;
+    const float *pl_color;
+    int n_global_lights;
+    const float *gl_dir;
+    const float *gl_color;
+    int all_opaque;           // every material has opacity >= 1
+    int any_reflective;
+    int has_scalar_prims;     // leaves hold unbatched triangles or solids
+    unsigned long long *stats;  // nullptr or 8 counters (nt_stats order)
+};
+
+// ---- launchers implemented in nt_kernels.hip ----
+struct NtLaunchInfo {
+    int n;                    // dimension
+    int nframes;
+    void *stream;             // hipStream_t
+};
+
+int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_launch_composite(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg);
+const char *nt_launch_error();

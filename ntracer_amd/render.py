@@ -1,0 +1,380 @@
+"""Mirror of the reference's ``ntracer.render`` module for the ray-cast path.
+
+Same names, argument meaning and error behaviour as the reference's C++ module
+(src/render.cpp), but every render goes through libntracer_hip.so to hand-written
+HIP kernels -- see include/ntracer_hip.h.  Types outside the path (pickling,
+capsules) are intentionally absent.
+"""
+import ctypes as C
+import threading
+
+from . import _lib
+from ._lib import LockedError  # noqa: F401  (re-export: render.LockedError)
+
+MAX_BITSIZE = 31          # render.cpp:48
+MAX_PIXELSIZE = 16        # render.cpp:50
+DEFAULT_SPECULAR_EXP = 8  # render.cpp:44
+
+
+class Channel(object):
+    """render.Channel(bit_size,f_r,f_g,f_b[,f_c=0,tfloat=False]) -- render.cpp:95-164."""
+    __slots__ = ("_v",)
+
+    def __init__(self, bit_size, f_r, f_g, f_b, f_c=0, tfloat=False):
+        bit_size = int(bit_size)
+        tfloat = bool(tfloat)
+        if tfloat:
+            if bit_size != 32:
+                raise ValueError('if "tfloat" is true, "bit_size" can only be 32')
+        else:
+            if bit_size > MAX_BITSIZE:
+                raise ValueError('"bit_size" cannot be greater than %d (unless "tfloat" is true)' % MAX_BITSIZE)
+            if bit_size < 1:
+                raise ValueError('"bit_size" cannot be less than 1')
+        object.__setattr__(self, "_v", (bit_size, float(f_r), float(f_g), float(f_b), float(f_c), tfloat))
+
+    bit_size = property(lambda s: s._v[0])
+    f_r = property(lambda s: C.c_float(s._v[1]).value)
+    f_g = property(lambda s: C.c_float(s._v[2]).value)
+    f_b = property(lambda s: C.c_float(s._v[3]).value)
+    f_c = property(lambda s: C.c_float(s._v[4]).value)
+    tfloat = property(lambda s: s._v[5])
+
+    def __setattr__(self, k, v):
+        raise AttributeError("readonly attribute")
+
+    def __repr__(self):
+        return "Channel(%d,%r,%r,%r,%r,%r)" % self._v
+
+
+class ImageFormat(object):
+    """render.ImageFormat(width,height,channels[,pitch=0,reversed=False]) -- render.cpp:167-288."""
+
+    def __init__(self, width, height, channels, pitch=0, reversed=False):
+        self.width = int(width)
+        self.height = int(height)
+        self.pitch = int(pitch)
+        self.reversed = bool(reversed)
+        self.set_channels(channels)
+        if self.width < 1 or self.height < 1:
+            raise ValueError("width and height must be at least 1")
+        if self.pitch < 0:
+            raise ValueError("pitch cannot be negative")
+        if self.pitch:
+            if self.pitch < self.width * self._bpp:
+                raise ValueError('"pitch" must be at least "width" times the size of one pixel in bytes')
+        else:
+            self.pitch = self.width * self._bpp
+
+    def set_channels(self, channels):
+        chans = []
+        bits = 0
+        for c in channels:
+            if not isinstance(c, Channel):
+                raise TypeError("object is not an instance of Channel")
+            bits += c.bit_size
+            chans.append(c)
+        if bits > MAX_PIXELSIZE * 8:
+            raise ValueError("Too many bytes per pixel. The maximum is %d." % MAX_PIXELSIZE)
+        self._channels = tuple(chans)
+        self._bpp = (bits + 7) // 8
+
+    @property
+    def channels(self):
+        return self._channels
+
+    @property
+    def bytes_per_pixel(self):
+        return self._bpp
+
+    def _as_struct(self):
+        arr = (_lib.NtChannel * max(len(self._channels), 1))()
+        for i, c in enumerate(self._channels):
+            arr[i].f_r, arr[i].f_g, arr[i].f_b, arr[i].f_c = c._v[1:5]
+            arr[i].bit_size = c.bit_size
+            arr[i].tfloat = 1 if c.tfloat else 0
+        f = _lib.NtImageFormat(self.width, self.height, self.pitch, len(self._channels), arr, 1 if self.reversed else 0)
+        f._keep = arr
+        return f
+
+
+class Color(object):
+    """render.Color(r,g,b) -- light.hpp:4-110, render.cpp:969-1152."""
+    __slots__ = ("r", "g", "b")
+
+    def __init__(self, r, g, b):
+        object.__setattr__(self, "r", C.c_float(r).value)
+        object.__setattr__(self, "g", C.c_float(g).value)
+        object.__setattr__(self, "b", C.c_float(b).value)
+
+    def __setattr__(self, k, v):
+        raise AttributeError("readonly attribute")
+
+    @staticmethod
+    def _coerce(v):
+        if isinstance(v, Color):
+            return v
+        r, g, b = v
+        return Color(r, g, b)
+
+    def __iter__(self):
+        return iter((self.r, self.g, self.b))
+
+    def __len__(self):
+        return 3
+
+    def __getitem__(self, i):
+        return (self.r, self.g, self.b)[i]
+
+    def __eq__(self, o):
+        try:
+            o = Color._coerce(o)
+        except (TypeError, ValueError):
+            return NotImplemented
+        return (self.r, self.g, self.b) == (o.r, o.g, o.b)
+
+    def __ne__(self, o):
+        r = self.__eq__(o)
+        return r if r is NotImplemented else not r
+
+    def __hash__(self):
+        return hash((self.r, self.g, self.b))
+
+    def __add__(self, o):
+        o = Color._coerce(o)
+        return Color(self.r + o.r, self.g + o.g, self.b + o.b)
+
+    def __sub__(self, o):
+        o = Color._coerce(o)
+        return Color(self.r - o.r, self.g - o.g, self.b - o.b)
+
+    def __neg__(self):
+        return Color(-self.r, -self.g, -self.b)
+
+    def __mul__(self, o):
+        if isinstance(o, (int, float)):
+            return Color(self.r * o, self.g * o, self.b * o)
+        o = Color._coerce(o)
+        return Color(self.r * o.r, self.g * o.g, self.b * o.b)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        if isinstance(o, (int, float)):
+            return Color(self.r / o, self.g / o, self.b / o)
+        o = Color._coerce(o)
+        return Color(self.r / o.r, self.g / o.g, self.b / o.b)
+
+    def apply(self, f):
+        return Color(f(self.r), f(self.g), f(self.b))
+
+    def __repr__(self):
+        return "Color(%r,%r,%r)" % (self.r, self.g, self.b)
+
+
+class Material(object):
+    """render.Material(color[,opacity=1,reflectivity=0,specular_intensity=1,specular_exp=8,
+    specular_color=(1,1,1)]) -- render.hpp:56-73, render.cpp:1166-1323."""
+
+    def __init__(self, color, opacity=1, reflectivity=0, specular_intensity=1, specular_exp=DEFAULT_SPECULAR_EXP,
+                 specular_color=(1, 1, 1)):
+        self.color = Color._coerce(color)
+        self.opacity = self._unit(opacity, "opacity")
+        self.reflectivity = self._unit(reflectivity, "reflectivity")
+        self.specular_intensity = self._unit(specular_intensity, "specular_intensity")
+        self.specular_exp = C.c_float(specular_exp).value
+        self.specular = Color._coerce(specular_color)
+
+    @staticmethod
+    def _unit(v, name):
+        v = C.c_float(v).value
+        if v < 0 or v > 1:
+            raise ValueError("%s must be between 0 and 1" % name)
+        return v
+
+    def _key(self):
+        return (tuple(self.color), tuple(self.specular), self.opacity, self.reflectivity, self.specular_intensity,
+                self.specular_exp)
+
+    def _as_struct(self):
+        m = _lib.NtMaterial()
+        m.color[:] = tuple(self.color)
+        m.specular[:] = tuple(self.specular)
+        m.opacity = self.opacity
+        m.reflectivity = self.reflectivity
+        m.specular_intensity = self.specular_intensity
+        m.specular_exp = self.specular_exp
+        return m
+
+    def __repr__(self):
+        return "Material(%r,%r,%r,%r,%r,%r)" % (tuple(self.color), self.opacity, self.reflectivity,
+                                                self.specular_intensity, self.specular_exp, tuple(self.specular))
+
+
+class Scene(object):
+    """render.Scene: the plugin interface `class scene` (render.hpp:8-26) as seen from Python.
+    Concrete scenes (tracern.BoxScene / CompositeScene) own an nt_scene_t handle."""
+    _handle = None
+
+    def __new__(cls, *a, **k):
+        if cls is Scene:
+            raise TypeError("the Scene type cannot be instantiated directly")
+        return object.__new__(cls)
+
+    def __del__(self):
+        h, self._handle = self._handle, None
+        if h:
+            try:
+                _lib.lib().nt_scene_destroy(h)
+            except Exception:
+                pass
+
+    def calculate_color(self, x, y, width, height):
+        """Scene.calculate_color(x,y,width,height) -- render.cpp:586-614."""
+        rgb = (C.c_float * 3)()
+        _lib.check(_lib.lib().nt_calculate_color(self._handle, int(x), int(y), int(width), int(height), rgb))
+        return Color(rgb[0], rgb[1], rgb[2])
+
+    @property
+    def locked(self):
+        return bool(_lib.lib().nt_scene_locked(self._handle))
+
+
+def _device_pointer(dest):
+    """(ptr, nbytes, device_index, stream) for a torch CUDA/HIP tensor, else None."""
+    if type(dest).__module__.split(".")[0] != "torch":
+        return None
+    if not getattr(dest, "is_cuda", False):
+        return None
+    import torch
+    if not dest.is_contiguous():
+        raise ValueError("device destination must be contiguous")
+    stream = torch.cuda.current_stream(dest.device).cuda_stream
+    return dest.data_ptr(), dest.numel() * dest.element_size(), dest.device.index, stream
+
+
+def _host_buffer(dest):
+    try:
+        mv = memoryview(dest)
+    except TypeError:
+        raise TypeError("dest must support the buffer protocol")
+    if mv.readonly:
+        raise BufferError("Object is not writable.")
+    if not mv.c_contiguous:
+        raise BufferError("dest must be C-contiguous")
+    n = mv.nbytes
+    arr = (C.c_char * n).from_buffer(dest) if n else None
+    return arr, n
+
+
+def _opts(device=-1, band_rank=0, band_world=1, compact=False, collect_stats=False, band_rows=0):
+    o = _lib.NtRenderOpts()
+    o.device = device
+    o.band_rank = band_rank
+    o.band_world = band_world
+    o.band_rows = band_rows
+    o.compact = 1 if compact else 0
+    o.strict_reference = 1
+    o.collect_stats = 1 if collect_stats else 0
+    return o
+
+
+class BlockingRenderer(object):
+    """render.BlockingRenderer([threads=-1]) -- render.cpp:769-923.
+
+    ``threads`` is accepted for compatibility; the frame is rendered by one HIP launch on
+    ``device`` (default: current device).  ``render`` returns True, or False if
+    ``signal_abort`` was called from another thread while it ran."""
+
+    def __init__(self, threads=-1, device=-1):
+        self.threads = int(threads)
+        self.device = int(device)
+        self._abort = C.c_int(0)
+        self._mut = threading.Lock()
+        self._busy = False
+
+    def render(self, dest, format, scene, band_rank=0, band_world=1, compact=False, collect_stats=False):
+        if not isinstance(format, ImageFormat):
+            raise TypeError("format must be an ImageFormat")
+        if not isinstance(scene, Scene):
+            raise TypeError("scene must be a Scene")
+        with self._mut:
+            if self._busy:
+                raise RuntimeError("the renderer is already running")
+            self._busy = True
+            self._abort.value = 0
+        try:
+            fmt = format._as_struct()
+            dev = _device_pointer(dest)
+            L = _lib.lib()
+            if dev is not None:
+                ptr, nbytes, index, stream = dev
+                opts = _opts(index, band_rank, band_world, compact, collect_stats)
+                _lib.check(L.nt_render_device(scene._handle, C.c_void_p(ptr), nbytes, C.byref(fmt), C.byref(opts),
+                                              C.c_void_p(stream)))
+                return True
+            arr, n = _host_buffer(dest)
+            opts = _opts(self.device, band_rank, band_world, compact, collect_stats)
+            r = _lib.check(L.nt_render(scene._handle, arr, n, C.byref(fmt), C.byref(opts), C.byref(self._abort)))
+            return r != _lib.NT_ABORTED
+        finally:
+            with self._mut:
+                self._busy = False
+
+    def signal_abort(self):
+        self._abort.value = 1
+
+
+class CallbackRenderer(object):
+    """render.CallbackRenderer([threads=0]) -- render.cpp:495-766: asynchronous render, ``callback(renderer)``
+    is invoked from a worker thread on completion (not after ``abort_render``)."""
+
+    def __init__(self, threads=0, device=-1):
+        self.threads = int(threads)
+        self.device = int(device)
+        self._abort = C.c_int(0)
+        self._mut = threading.Lock()
+        self._worker = None
+
+    def begin_render(self, dest, format, scene, callback):
+        if not isinstance(format, ImageFormat):
+            raise TypeError("format must be an ImageFormat")
+        if not isinstance(scene, Scene):
+            raise TypeError("scene must be a Scene")
+        arr, n = _host_buffer(dest)
+        fmt = format._as_struct()
+        if fmt.pitch * fmt.height > n:
+            raise ValueError("the buffer is too small for an image with the given dimensions")
+        with self._mut:
+            if self._worker is not None and self._worker.is_alive():
+                raise RuntimeError("the renderer is already running")
+            self._abort.value = 0
+            L = _lib.lib()
+            _lib.check(L.nt_scene_lock(scene._handle))     # sc.lock() before returning (render.cpp:688)
+            opts = _opts(self.device)
+
+            def work():
+                try:
+                    r = L.nt_render(scene._handle, arr, n, C.byref(fmt), C.byref(opts), C.byref(self._abort))
+                finally:
+                    L.nt_scene_unlock(scene._handle)
+                if r == _lib.NT_OK:
+                    callback(self)
+
+            self._worker = threading.Thread(target=work, daemon=True)
+            self._worker.start()
+
+    def abort_render(self):
+        w = self._worker
+        if w is not None and w.is_alive():
+            self._abort.value = 1
+            w.join()
+        self._abort.value = 0
+
+
+def get_optimized_tracern(dimension):
+    """render.get_optimized_tracern(dimension) -- render.cpp:1659-1674.  The specialisation for
+    3..8 dimensions happens inside the HIP library (template<int N> kernels); the Python surface is
+    one module."""
+    from . import tracern
+    return tracern
