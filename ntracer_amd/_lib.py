@@ -111,6 +111,28 @@ SYMBOLS = [
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.  Two HIP runtimes in
+    one process cannot both open the GPU, so when torch is installed we load ITS runtime first; our
+    library's NEEDED libamdhip64.so.7 then binds to that copy by soname.  Without torch (a plain C++
+    host) the system runtime in /opt/rocm is used.  Set NTRACER_HIP_SYSTEM_RUNTIME=1 to skip this."""
+    if os.environ.get("NTRACER_HIP_SYSTEM_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load the HIP library.  Fails loudly when it has not been built."""
     global _lib
@@ -119,6 +141,7 @@ def lib():
             raise ImportError(
                 "libntracer_hip.so is missing (%s): build it with `python -m ntracer_amd.build` "
                 "(hipcc --offload-arch=gfx950).  The ray-cast path has no CPU fallback." % LIB_PATH)
+        _preload_torch_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(l, name)      # AttributeError if the ABI is incomplete

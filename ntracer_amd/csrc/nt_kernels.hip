@@ -36,7 +36,8 @@ __device__ __forceinline__ void pack_pixel(float r, float g, float b, const NtTa
     int off = 0;
     for (int k = 0; k < tg.nchannels; ++k) {
         const NtChanDev c = tg.chans[k];
-        float v = ((c.f_r * r + c.f_g * g) + c.f_b * b) + c.f_c;
+        // association order of the reference build, pinned by tests/golden/packing_box3.npz (see oracle)
+        float v = (c.f_g * g + c.f_b * b) + (c.f_r * r + c.f_c);
         v = v > 0.0f ? v : 0.0f;     // simd::clamp = min(max(v,0),1), SSE NaN rule
         v = v < 1.0f ? v : 1.0f;
         uint64_t ival;

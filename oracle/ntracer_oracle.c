@@ -288,6 +288,9 @@ static int leaf_intersects(ctx_t *cx, int node, const ray_t *target, target_t sk
     float dist = 0;
     int i = 0;
     int hit = 0;
+    ray_t clean_tmp;
+    /* the reference hands o_hit.normal itself to the tests of the first loop (tracer.hpp:1001,1020) */
+    ray_t *scratch = s->clean_normals ? &clean_tmp : &o_hit->normal;
     if (cx->c) cx->c->leaves++;
 
     for (; i < size; ++i) {
@@ -295,31 +298,33 @@ static int leaf_intersects(ctx_t *cx, int node, const ray_t *target, target_t sk
         if ((item & 3) == NTO_KIND_BATCH) {
             if (!has(checked, item)) {
                 int index = skip.item == item ? skip.lane : -1;
-                dist = batch_intersects(cx, item >> 2, target, &o_hit->normal, &index, o_hit->dist);
+                dist = batch_intersects(cx, item >> 2, target, scratch, &index, o_hit->dist);
                 if (dist != 0.0f) {
                     target_t tg = {item, index};
                     if (opaque(s, tg)) {
                         o_hit->dist = dist;
                         o_hit->target = tg;
+                        if (scratch != &o_hit->normal) o_hit->normal = *scratch;
                         hit = 1;
-                        break;   /* goto hit (i is NOT advanced: the same item is re-visited but now `checked`... */
+                        break;   /* goto hit: `i` is NOT advanced (see below) */
                     }
-                    isect_t th; th.dist = dist; th.target = tg; th.normal = o_hit->normal;
+                    isect_t th; th.dist = dist; th.target = tg; th.normal = *scratch;
                     il_add(t_hits, &th);
                 }
                 pl_add(checked, item);
             }
         } else if (item != skip.item && !has(checked, item)) {
-            dist = primitive_intersects(cx, item, target, &o_hit->normal, o_hit->dist);
+            dist = primitive_intersects(cx, item, target, scratch, o_hit->dist);
             if (dist != 0.0f) {
                 target_t tg = {item, -1};
                 if (opaque(s, tg)) {
                     o_hit->dist = dist;
                     o_hit->target = tg;
+                    if (scratch != &o_hit->normal) o_hit->normal = *scratch;
                     hit = 1;
                     break;
                 }
-                isect_t th; th.dist = dist; th.target = tg; th.normal = o_hit->normal;
+                isect_t th; th.dist = dist; th.target = tg; th.normal = *scratch;
                 il_add(t_hits, &th);
             }
             pl_add(checked, item);
@@ -717,7 +722,10 @@ void nto_pack_pixel(const float rgb[3], int nchannels, const nto_channel *ch, in
     uint64_t temp[2] = {0, 0};
     int b_offset = 0;
     for (int k = 0; k < nchannels; ++k) {
-        float v = ((ch[k].f_r * rgb[0] + ch[k].f_g * rgb[1]) + ch[k].f_b * rgb[2]) + ch[k].f_c;
+        /* `f_r*r + f_g*g + f_b*b + f_c` (render.cpp:427) is compiled -ffast-math in the reference; the
+           association its build uses, pinned bit-exactly by tests/golden/packing_box3.npz (31-bit and
+           30-bit channels), is (f_g*g + f_b*b) + (f_r*r + f_c). */
+        float v = (ch[k].f_g * rgb[1] + ch[k].f_b * rgb[2]) + (ch[k].f_r * rgb[0] + ch[k].f_c);
         /* simd::clamp(x,0,1) = min(max(x,0),1) with SSE semantics: NaN -> second operand */
         v = v > 0.0f ? v : 0.0f;
         v = v < 1.0f ? v : 1.0f;
