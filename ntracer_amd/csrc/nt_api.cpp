@@ -82,7 +82,8 @@ struct DeviceState {
 
 struct Format {                          // validated image_format (render.cpp:167-172)
     int width = 0, height = 0, pitch = 0, bpp = 0, reversed = 0;
-    std::vector<NtChanDev> chans;
+    int pack_mode = NT_PACK_GENERIC;
+    std::vector<NtChanDev> chans;        // live channels only (all-zero channels contribute no bits)
 };
 
 }  // namespace
@@ -136,15 +137,23 @@ int parse_format(const nt_image_format *f, Format &out) {
             if (c.bit_size > NT_MAX_BITSIZE) return fail(NT_E_INVALID, "\"bit_size\" cannot be greater than %d (unless \"tfloat\" is true)", NT_MAX_BITSIZE);
             if (c.bit_size < 1) return fail(NT_E_INVALID, "\"bit_size\" cannot be less than 1");
         }
-        bits += c.bit_size;
         NtChanDev d;
         d.f_r = c.f_r; d.f_g = c.f_g; d.f_b = c.f_b; d.f_c = c.f_c;
         d.bits = c.bit_size;
         d.tfloat = c.tfloat ? 1u : 0u;
-        out.chans.push_back(d);
+        d.offset = (uint32_t)bits;
+        d.maxval = c.tfloat ? 0u : (0xffffffffu >> (32 - c.bit_size));
+        bits += c.bit_size;
+        // clamp((0*g + 0*b) + (0*r + 0)) is 0 for every colour (NaN included): such a channel (the X of
+        // RGBX8, padding) writes no bits, so it is dropped from the device table
+        const bool dead = c.f_r == 0.0f && c.f_g == 0.0f && c.f_b == 0.0f && c.f_c == 0.0f;
+        if (!dead) out.chans.push_back(d);
     }
     if (bits > NT_MAX_PIXELSIZE * 8) return fail(NT_E_INVALID, "Too many bytes per pixel. The maximum is %d.", NT_MAX_PIXELSIZE);
     out.bpp = (int)((bits + 7) / 8);
+    out.pack_mode = NT_PACK_GENERIC;
+    if (out.chans.size() <= 4 && bits <= 32) out.pack_mode = NT_PACK_WORD32;
+    else if (out.chans.size() <= 4 && bits <= 64) out.pack_mode = NT_PACK_WORD64;
     if (f->width < 1 || f->height < 1) return fail(NT_E_INVALID, "width and height must be at least 1");
     if (f->pitch < 0) return fail(NT_E_INVALID, "pitch cannot be negative");
     out.width = f->width;
@@ -397,6 +406,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         if (int r = chan_table(ds, f, chans)) return r;
         tg.chans = chans;
         tg.nchannels = (int)f.chans.size();
+        tg.pack_mode = f.pack_mode;
         tg.bpp = f.bpp;
         tg.reversed = f.reversed;
         tg.pitch = f.pitch;

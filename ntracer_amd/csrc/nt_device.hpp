@@ -13,11 +13,18 @@
 // reference: LIGHT_THRESHOLD (src/tracer.hpp:31)
 #define NT_LIGHT_THRESHOLD (1.0f / 512.0f)
 
-struct NtChanDev {          // render.cpp:95-99 channel
+struct NtChanDev {          // render.cpp:95-99 channel, plus host-precomputed packing constants
     float f_r, f_g, f_b, f_c;
     uint32_t bits;
     uint32_t tfloat;
+    uint32_t offset;        // first bit of the channel, counted from the pixel's most significant bit
+    uint32_t maxval;        // 0xffffffff >> (32 - bits): the integer scale of render.cpp:439
 };
+
+// how a pixel is assembled (chosen on the host from the format)
+#define NT_PACK_GENERIC 0   // up to 128 bits, any number of channels
+#define NT_PACK_WORD32 1    // <= 32 bits and <= 4 live channels: one 32-bit container, unrolled
+#define NT_PACK_WORD64 2    // <= 64 bits and <= 4 live channels: one 64-bit container, unrolled
 
 // Where the pixels of one launch go.  Rows are dealt to ranks in bands of `band_rows`
 // (RENDER_CHUNK_SIZE, render.cpp:43): owned row r -> image row
@@ -27,6 +34,7 @@ struct NtTarget {
     long long frame_stride;   // bytes between frames (blockIdx.z)
     const NtChanDev *chans;
     int nchannels, bpp, reversed, pitch;
+    int pack_mode;            // NT_PACK_*; channels whose value is identically 0 are dropped from `chans`
     int width, height;        // view size: set_view_size(w,h) (tracer.hpp:65-69)
     float half_w, half_h, fovI;
     int band_rank, band_world, band_rows, compact;

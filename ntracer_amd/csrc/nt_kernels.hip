@@ -30,33 +30,77 @@ thread_local char g_launch_error[256] = "";
 // --------------------------------------------------------------------------------------
 // pixel packing: render.cpp:419-462
 // --------------------------------------------------------------------------------------
+
+// lround(v * double(maxval)) (render.cpp:439) for v in [0,1], exactly, without f64 when the double
+// product is exact (bits <= 29): v = m * 2^-s, so the answer is round-half-up(m * maxval / 2^s).
+__device__ __forceinline__ uint32_t quantize(float v, uint32_t maxval, uint32_t bits) {
+    const uint32_t u = __float_as_uint(v);
+    const uint32_t e = u >> 23;                                  // v >= 0: no sign bit
+    const uint32_t m = (u & 0x7fffffu) | (e ? 0x800000u : 0u);
+    const uint32_t s = (e ? 150u : 149u) - e;                    // >= 23 because v <= 1
+    if (bits <= 8) {
+        const uint32_t p = m * maxval;                           // < 2^32
+        return s > 32u ? 0u : (((p >> (s - 1u)) + 1u) >> 1);
+    }
+    if (bits <= 29) {
+        const uint64_t p = (uint64_t)m * maxval;                 // < 2^53
+        return s > 56u ? 0u : (uint32_t)(((p >> (s - 1u)) + 1u) >> 1);
+    }
+    return (uint32_t)llround((double)v * (double)maxval);        // 30/31-bit channels: the f64 product rounds
+}
+
+__device__ __forceinline__ uint32_t channel_value(const NtChanDev &c, float r, float g, float b) {
+    // association order of the reference build, pinned by tests/golden/packing_box3.npz (see oracle)
+    float v = (c.f_g * g + c.f_b * b) + (c.f_r * r + c.f_c);
+    v = v > 0.0f ? v : 0.0f;     // simd::clamp = min(max(v,0),1), SSE NaN rule
+    v = v < 1.0f ? v : 1.0f;
+    return c.tfloat ? __float_as_uint(v) : quantize(v, c.maxval, c.bits);
+}
+
+// generic: up to 128 bits, any channel count
 __device__ __forceinline__ void pack_pixel(float r, float g, float b, const NtTarget &tg, uint64_t &hi, uint64_t &lo) {
     hi = 0;
     lo = 0;
-    int off = 0;
     for (int k = 0; k < tg.nchannels; ++k) {
         const NtChanDev c = tg.chans[k];
-        // association order of the reference build, pinned by tests/golden/packing_box3.npz (see oracle)
-        float v = (c.f_g * g + c.f_b * b) + (c.f_r * r + c.f_c);
-        v = v > 0.0f ? v : 0.0f;     // simd::clamp = min(max(v,0),1), SSE NaN rule
-        v = v < 1.0f ? v : 1.0f;
-        uint64_t ival;
-        if (c.tfloat) {
-            ival = __float_as_uint(v);
-        } else {
-            ival = (uint64_t)llround((double)v * (double)(0xffffffffu >> (32 - c.bits)));
-        }
+        const uint64_t ival = channel_value(c, r, g, b);
         const int bits = (int)c.bits;
+        const int off = (int)c.offset;
         const int rm = off & 63;
         const int sh = 64 - rm - bits;
         if (off < 64) {
             hi |= sh >= 0 ? ival << sh : ival >> -sh;
-            if (rm + bits > 64) lo = ival << (128 - rm - bits);
+            if (rm + bits > 64) lo |= ival << (128 - rm - bits);
         } else {
             lo |= ival << sh;    // total <= 128 bits, so sh >= 0 here
         }
-        off += bits;
     }
+}
+
+// <= 4 live channels in one 32-bit container (RGBX8, RGB565, RGB888, ...): fully unrolled, the
+// channel constants stay in SGPRs
+__device__ __forceinline__ uint32_t pack_word32(float r, float g, float b, const NtTarget &tg) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < tg.nchannels) {
+            const NtChanDev c = tg.chans[k];
+            w |= channel_value(c, r, g, b) << (32u - c.offset - c.bits);
+        }
+    }
+    return w;
+}
+
+__device__ __forceinline__ uint64_t pack_word64(float r, float g, float b, const NtTarget &tg) {
+    uint64_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < tg.nchannels) {
+            const NtChanDev c = tg.chans[k];
+            w |= (uint64_t)channel_value(c, r, g, b) << (64u - c.offset - c.bits);
+        }
+    }
+    return w;
 }
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
@@ -143,9 +187,23 @@ __device__ __forceinline__ void emit_pixel(const NtTarget &tg, const PixelRef &p
         o[2] = b;
         return;
     }
+    uint8_t *p = tg.dest + pr.offset;
+    if (tg.pack_mode == NT_PACK_WORD32) {
+        const uint32_t w = pack_word32(r, g, b, tg);
+        if (tg.bpp == 4 && tg.aligned4) {
+            *reinterpret_cast<uint32_t *>(p) = tg.reversed ? w : bswap32(w);     // one coalesced dword per lane
+            return;
+        }
+        store_pixel(p, tg, (uint64_t)w << 32, 0);
+        return;
+    }
+    if (tg.pack_mode == NT_PACK_WORD64) {
+        store_pixel(p, tg, pack_word64(r, g, b, tg), 0);
+        return;
+    }
     uint64_t hi, lo;
     pack_pixel(r, g, b, tg, hi, lo);
-    store_pixel(tg.dest + pr.offset, tg, hi, lo);
+    store_pixel(p, tg, hi, lo);
 }
 
 // --------------------------------------------------------------------------------------
@@ -190,31 +248,78 @@ __device__ __forceinline__ void primary_dir(const NtTarget &tg, const float (&ri
 }
 
 // box_scene::calculate_color + hypercube_intersects (tracer.hpp:101-152).
-// Every lane walks all N candidate faces under predication (no divergent early exit).
+//
+// The reference tries the entry face of every axis i in ascending order; face i is the hit when
+// dist_i = (s_i - o_i)/d_i > 0 and |o_j + d_j*dist_i| <= 1+FUZZ for all j != i.  The same predicate is
+// evaluated here, bit for bit, but in an order that lets whole waves skip work:
+//   1. a ray whose distance from the centre exceeds the cube's circumradius (with a 0.1 % margin, far
+//      above any rounding) cannot satisfy the predicate for any face -> waves of such rays skip all faces;
+//   2. the AND over j is order-independent, so each face is first checked against ONE wave-uniform axis K
+//      (the axis entered last by the wave's first candidate ray); faces that fail it for every lane --
+//      all but one or two in a coherent wave -- skip the remaining N-2 checks;
+//   3. faces no lane can enter (dist <= 0 for the whole wave) skip their division.
 template <int N>
 __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir)[N], float &r, float &g, float &b) {
     bool done = false;     // a face passed the slab test (hit, or dist >= cutoff)
     float shade = 0.0f;
+
+    float osq = o[0] * o[0], od = o[0] * dir[0];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const float di = dir[i];
-        const float s = di < 0.0f ? 1.0f : -1.0f;
-        const float dist = (s - o[i]) / di;
-        bool ok = !done && di != 0.0f && dist > 0.0f;
+    for (int j = 1; j < N; ++j) { osq += o[j] * o[j]; od += o[j] * dir[j]; }
+    const float rad2 = (float)N * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
+    const bool maybe = !((osq - od * od) > rad2);            // NaN -> maybe
+
+    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+        float dist[N];
+        bool cand[N];
+        float dmax = -1.0f;
+        int kmax = -1;
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (j != i) {
-                const float p = dir[j] * dist + o[j];
-                ok = ok && !(fabsf(p) > (1.0f + NT_FUZZ));
+        for (int i = 0; i < N; ++i) {
+            const float di = dir[i];
+            const float s = di < 0.0f ? 1.0f : -1.0f;
+            const float num = s - o[i];
+            // dist > 0 needs a non-zero numerator with the sign of di
+            const bool pre = maybe && di != 0.0f && ((num > 0.0f && di > 0.0f) || (num < 0.0f && di < 0.0f));
+            dist[i] = 0.0f;
+            cand[i] = false;
+            if (__builtin_amdgcn_ballot_w64(pre) != 0ull) {
+                dist[i] = num / di;
+                cand[i] = pre && dist[i] > 0.0f;
             }
+            if (cand[i] && dist[i] > dmax) { dmax = dist[i]; kmax = i; }
         }
-        if (ok) {
-            done = true;
-            // `if(dist >= cutoff) return 0` with cutoff = FLT_MAX (tracer.hpp:142): treated as a miss
-            if (dist >= FLT_MAX) shade = -1.0f;
-            else {
-                const float sine = di * s;                      // dot(dir, s*e_i)
-                shade = sine <= 0.0f ? -sine : 0.0f;
+        const unsigned long long has = __builtin_amdgcn_ballot_w64(kmax >= 0);
+        if (has != 0ull) {
+            const int K = __builtin_amdgcn_readlane(kmax, (int)__builtin_ctzll(has));
+            float dK = dir[0], oK = o[0];
+#pragma unroll
+            for (int k = 1; k < N; ++k) if (K == k) { dK = dir[k]; oK = o[k]; }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                bool ok = cand[i] && !done;
+                if (i != K) {
+                    const float p = dK * dist[i] + oK;
+                    ok = ok && !(fabsf(p) > (1.0f + NT_FUZZ));
+                }
+                if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        if (j != i) {
+                            const float p = dir[j] * dist[i] + o[j];
+                            ok = ok && !(fabsf(p) > (1.0f + NT_FUZZ));
+                        }
+                    }
+                    if (ok) {
+                        done = true;
+                        // `if(dist >= cutoff) return 0` with cutoff = FLT_MAX (tracer.hpp:142): a miss
+                        if (dist[i] >= FLT_MAX) shade = -1.0f;
+                        else {
+                            const float sine = dir[i] * (dir[i] < 0.0f ? 1.0f : -1.0f);   // dot(dir, s*e_i)
+                            shade = sine <= 0.0f ? -sine : 0.0f;
+                        }
+                    }
+                }
             }
         }
     }
