@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -76,7 +77,8 @@ struct DeviceState {
     DevBuf nodes, items, batch_recs, batch_mats, tri_recs, tri_mats, solid_recs, solid_types, solid_mats, materials, aabb;
     DevBuf lights;                       // pl_pos | pl_color | gl_dir | gl_color
     unsigned long long lights_version = 0;
-    DevBuf framebuffer, cams, probes, stats;
+    DevBuf framebuffer, cams, probes, stats, counter;
+    int cu_count = 0;
     std::vector<std::unique_ptr<ChanTable>> chan_tables;
 };
 
@@ -221,6 +223,7 @@ int device_state(nt_scene *s, int dev, DeviceState *&out) {
         auto ds = std::make_unique<DeviceState>();
         ds->device = dev;
         HIP_TRY(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
+        HIP_TRY(hipDeviceGetAttribute(&ds->cu_count, hipDeviceAttributeMultiprocessorCount, dev));
         it = s->devs.emplace(dev, std::move(ds)).first;
     }
     out = it->second.get();
@@ -427,11 +430,30 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     li.n = s->n;
     li.nframes = job.nframes;
     li.stream = job.stream;
+    li.persist_counter = nullptr;
+    li.persist_cams = nullptr;
+    li.cu_count = ds->cu_count;
+    li.kernel_choice = 0;
+    if (const char *kc = getenv("NTRACER_COMPOSITE_KERNEL")) li.kernel_choice = atoi(kc);
     int r;
     if (s->composite) {
         NtCompositeDev c;
         fill_composite(s, ds, c, job.stats);
         if (c.root < 0) c.root = -1;
+        const bool lean = !c.n_point_lights && !c.n_global_lights && !c.any_reflective && !c.has_scalar_prims;
+        if (lean && !job.stats && !job.colors_out && s->n <= NT_MAX_FIXED_DIM && li.kernel_choice != 2) {
+            // persistent kernel: a zeroed work counter and the camera table in device memory (stream ordered)
+            if (int e = ds->counter.ensure(8)) return e;
+            HIP_TRY(hipMemsetAsync(ds->counter.p, 0, 8, job.stream));
+            li.persist_counter = ds->counter.p;
+            if (job.cam_buf) {
+                li.persist_cams = job.cam_buf;
+            } else {
+                if (int e = ds->cams.ensure(sizeof(float) * 4 * s->n)) return e;
+                HIP_TRY(hipMemcpyAsync(ds->cams.p, cam.inl, sizeof(float) * 4 * s->n, hipMemcpyHostToDevice, job.stream));
+                li.persist_cams = (const float *)ds->cams.p;
+            }
+        }
         r = nt_launch_composite(li, cam, c, tg);
     } else {
         r = nt_launch_box(li, cam, tg);
@@ -607,7 +629,7 @@ void nt_scene_destroy(nt_scene_t *s) {
         if (hipSetDevice(ds->device) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
         for (DevBuf *b : {&ds->nodes, &ds->items, &ds->batch_recs, &ds->batch_mats, &ds->tri_recs, &ds->tri_mats, &ds->solid_recs,
-                          &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams,
+                          &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams, &ds->counter,
                           &ds->probes, &ds->stats})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);

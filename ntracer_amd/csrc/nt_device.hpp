@@ -101,6 +101,12 @@ struct NtLaunchInfo {
     int n;                    // dimension
     int nframes;
     void *stream;             // hipStream_t
+    // persistent composite kernel (optional): a zeroed 8-byte work counter, the camera table
+    // [nframes][4][n] in device memory, and the CU count of the device
+    void *persist_counter;
+    const float *persist_cams;
+    int cu_count;
+    int kernel_choice;        // 0: default (packet kernel for lean scenes), 1: persistent per-lane kernel, 2: tile kernel
 };
 
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);

@@ -491,6 +491,37 @@ __device__ __forceinline__ float simplex_batch_form(const SimplexRec<N> &s, cons
     return ok ? t : 0.0f;
 }
 
+// The same predicate in two stages, for wave-uniform records: stage 1 is the plane part (denom, t); the
+// point-in-simplex part only runs if some lane can still accept this simplex (`want`: the caller's remaining
+// conditions, e.g. t < current cutoff).  A lane that fails stage 1 or `want` is rejected either way, so the
+// result is the one simplex_batch_form gives.
+template <int N, typename Want>
+__device__ __forceinline__ float simplex_batch_form_staged(const SimplexRec<N> &s, const float (&o)[N], const float (&d)[N], Want want) {
+    float denom = s.nrm(0) * d[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) denom = denom + s.nrm(k) * d[k];
+    float no = s.nrm(0) * o[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) no = no + s.nrm(k) * o[k];
+    const float t = -(no + s.d()) / denom;
+    bool ok = denom != 0.0f && t >= 0.0f;
+    if (__builtin_amdgcn_ballot_w64(ok && want(t)) == 0ull) return 0.0f;
+    float pside[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) pside[k] = s.p1(k) - (o[k] + t * d[k]);
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+        float area = s.edge(i, 0) * pside[0];
+#pragma unroll
+        for (int k = 1; k < N; ++k) area = area + s.edge(i, k) * pside[k];
+        ok = ok && area >= -NT_FUZZ;
+        tot += area;
+    }
+    ok = ok && tot <= (1.0f + NT_FUZZ);
+    return ok ? t : 0.0f;
+}
+
 // triangle::intersects (tracer.hpp:411-440): scalar form with the early rejects
 template <int N>
 __device__ __forceinline__ float simplex_scalar_form(const SimplexRec<N> &s, const float (&o)[N], const float (&d)[N], float cutoff) {
@@ -594,14 +625,45 @@ __device__ __noinline__ float solid_intersects(const NtCompositeDev &sc, int idx
     return dist;
 }
 
-// Per-wave LDS scratch: a traversal stack [depth][64] of (node, t) pairs and the ray table
-// [N][64] of (origin[axis], 1/direction[axis]) pairs used by the axis-indexed branch step.
-// 8-byte entries at lane stride: ds_read_b64/ds_write_b64 are conflict free whatever level
-// each lane is at (bank = f(lane) only).
+// Per-wave LDS scratch, all lane-major so that an access is conflict free whatever level / slot each lane is at:
+//   stack[level][64]  4-byte entries: the index of a branch whose far side is still pending
+//                     (t and the far child are recomputed from the node record on pop -- same inputs, same bits)
+//   ray[N][64]        (origin[axis], 1/direction[axis]) pairs for the axis-indexed branch step
+//   mbox[NT_MBOX][64] direct-mapped mailbox of recently tested leaf items (the reference's `checked`
+//                     list, tracer.hpp:782,832: a primitive spanning several leaves is tested once)
+#define NT_MBOX 16
 struct WaveLds {
-    float2 *stack;     // stack[level*64 + lane]
+    int *stack;        // stack[level*64 + lane]
     float2 *ray;       // ray[axis*64 + lane]
+    int *mbox;         // mbox[slot*64 + lane]
 };
+
+__device__ __forceinline__ size_t wave_lds_bytes(int stack_depth, int n) {
+    return (size_t)64 * ((size_t)stack_depth * 4 + (size_t)n * 8 + (size_t)NT_MBOX * 4);
+}
+
+__device__ __forceinline__ WaveLds wave_lds(char *base, int wave, int stack_depth, int n) {
+    char *p = base + (size_t)wave * wave_lds_bytes(stack_depth, n);
+    WaveLds w;
+    w.ray = reinterpret_cast<float2 *>(p);                                     // 8-byte aligned first
+    w.stack = reinterpret_cast<int *>(p + (size_t)64 * n * 8);
+    w.mbox = w.stack + (size_t)64 * stack_depth;
+    return w;
+}
+
+__device__ __forceinline__ void mbox_reset(const WaveLds &w, int lane) {
+#pragma unroll
+    for (int k = 0; k < NT_MBOX; ++k) w.mbox[k * 64 + lane] = -1;
+}
+
+// true when `item` was already tested for this ray (then re-testing cannot change the hit: the cutoff only
+// shrinks); otherwise records it.  Evictions only cause harmless re-tests.
+__device__ __forceinline__ bool mbox_seen(const WaveLds &w, int lane, int item) {
+    const int slot = ((item >> 2) & (NT_MBOX - 1)) * 64 + lane;
+    const bool seen = w.mbox[slot] == item;
+    w.mbox[slot] = item;
+    return seen;
+}
 
 template <int N>
 __device__ __forceinline__ void setup_ray_table(const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N]) {
@@ -617,13 +679,14 @@ __device__ __forceinline__ void setup_ray_table(const WaveLds &w, int lane, cons
 // One leaf (kd_leaf<Store,true>::intersects, tracer.hpp:977-1086) for all-opaque scenes: every
 // hit tightens the cutoff, so the two-loop structure collapses to "keep the nearest, first wins".
 template <int N, bool FEAT, bool STATS>
-__device__ __forceinline__ bool leaf_closest(const NtCompositeDev &sc, int start, int count, const float (&o)[N], const float (&d)[N],
-                                             int skip_item, int skip_lane, Hit &hit, Stats &st) {
+__device__ __forceinline__ bool leaf_closest(const NtCompositeDev &sc, const WaveLds &w, int lane, int start, int count,
+                                             const float (&o)[N], const float (&d)[N], int skip_item, int skip_lane, Hit &hit, Stats &st) {
     bool improved = false;
     for (int i = 0; i < count; ++i) {
         const int item = sc.items[start + i];
         const int kind = item & 3;
         const int idx = item >> 2;
+        if (mbox_seen(w, lane, item)) continue;
         if (kind == 0) {
             const int sl = item == skip_item ? skip_lane : -1;
             float min_t = hit.dist;
@@ -662,12 +725,20 @@ __device__ __forceinline__ bool leaf_closest(const NtCompositeDev &sc, int start
 //     (`dirty`: number of bottom stack entries that have seen an improvement);
 //   - `(hit && o_hit.dist <= t) || !n_far` => the frame returns (pop again), otherwise continue into far
 //     with t_near = t; far == -1 encodes the `!n_far` case so that t_far is always the top entry's t.
+// split distance of branch `nd` for the ray in the table: (split - origin[axis]) * invdir[axis] (tracer.hpp:1197)
+__device__ __forceinline__ float branch_t(const WaveLds &w, int lane, const NtNode &nd, bool &gt) {
+    const float2 oi = w.ray[nd.axis * 64 + lane];
+    gt = oi.x > nd.split;
+    return (nd.split - oi.x) * oi.y;
+}
+
 template <int N, bool FEAT, bool STATS>
 __device__ __forceinline__ bool trace_closest(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
                                               float t_near, float t_far_root, int skip_item, int skip_lane, Hit &hit, Stats &st) {
     hit.dist = FLT_MAX;
     hit.item = -1;
     hit.lane = -1;
+    mbox_reset(w, lane);
     int node = sc.root;
     int sp = 0;
     int dirty = 0;
@@ -678,7 +749,7 @@ __device__ __forceinline__ bool trace_closest(const NtCompositeDev &sc, const Wa
             const NtNode nd = sc.nodes[node];
             if (nd.axis < 0) {
                 if (STATS) st.leaves += 1;
-                if (leaf_closest<N, FEAT, STATS>(sc, nd.left, nd.right, o, d, skip_item, skip_lane, hit, st)) dirty = sp;
+                if (leaf_closest<N, FEAT, STATS>(sc, w, lane, nd.left, nd.right, o, d, skip_item, skip_lane, hit, st)) dirty = sp;
                 node = -1;
                 break;
             }
@@ -695,7 +766,7 @@ __device__ __forceinline__ bool trace_closest(const NtCompositeDev &sc, const Wa
                 if (t < t_near) { node = n_far; continue; }
                 if (n_near >= 0) {
                     if (sp < max_sp) {              // always true: depth <= tree depth (host-checked)
-                        w.stack[sp * 64 + lane] = make_float2(__int_as_float(n_far), t);
+                        w.stack[sp * 64 + lane] = node;
                         ++sp;
                     }
                     t_far = t;
@@ -712,15 +783,21 @@ __device__ __forceinline__ bool trace_closest(const NtCompositeDev &sc, const Wa
         bool resumed = false;
         while (sp > 0) {
             --sp;
-            const float2 e = w.stack[sp * 64 + lane];
-            const int far = __float_as_int(e.x);
-            const float t = e.y;
+            const NtNode nd = sc.nodes[w.stack[sp * 64 + lane]];
+            bool gt;
+            const float t = branch_t(w, lane, nd, gt);
+            const int far = gt ? nd.left : nd.right;
             const bool near_hit = sp < dirty;
             if (dirty > sp) dirty = sp;
             if ((near_hit && hit.dist <= t) || far < 0) continue;     // frame returns `hit`
             node = far;
             t_near = t;
-            t_far = sp > 0 ? w.stack[(sp - 1) * 64 + lane].y : t_far_root;
+            t_far = t_far_root;
+            if (sp > 0) {
+                const NtNode up = sc.nodes[w.stack[(sp - 1) * 64 + lane]];
+                bool g2;
+                t_far = branch_t(w, lane, up, g2);
+            }
             resumed = true;
             break;
         }
@@ -802,7 +879,7 @@ __device__ __noinline__ bool trace_occluded(const NtCompositeDev &sc, const Wave
                 if (t < t_near) { node = n_far; continue; }
                 if (n_near >= 0) {
                     if (sp < max_sp) {
-                        w.stack[sp * 64 + lane] = make_float2(__int_as_float(n_far), t);
+                        w.stack[sp * 64 + lane] = node;
                         ++sp;
                     }
                     t_far = t;
@@ -819,13 +896,19 @@ __device__ __noinline__ bool trace_occluded(const NtCompositeDev &sc, const Wave
         bool resumed = false;
         while (sp > 0) {
             --sp;
-            const float2 e = w.stack[sp * 64 + lane];
-            const int far = __float_as_int(e.x);
-            const float t = e.y;
+            const NtNode nd = sc.nodes[w.stack[sp * 64 + lane]];
+            bool gt;
+            const float t = branch_t(w, lane, nd, gt);
+            const int far = gt ? nd.left : nd.right;
             if (t < ldistance || far < 0) continue;             // frame returns false
             node = far;
             t_near = t;
-            t_far = sp > 0 ? w.stack[(sp - 1) * 64 + lane].y : FLT_MAX;
+            t_far = FLT_MAX;
+            if (sp > 0) {
+                const NtNode up = sc.nodes[w.stack[(sp - 1) * 64 + lane]];
+                bool g2;
+                t_far = branch_t(w, lane, up, g2);
+            }
             resumed = true;
             break;
         }
@@ -924,6 +1007,40 @@ struct Level {      // one frame of the base_color/ray_color recursion that is w
     float spec_a, refl;
 };
 
+// ray_color's miss branch (tracer.hpp:1866-1867)
+template <int N>
+__device__ __forceinline__ Color3 background_color(const NtCompositeDev &sc, const float (&d)[N]) {
+    // target.direction[bg_gradient_axis]: select chain instead of indexing registers
+    float iv = d[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) iv = sc.bg_axis == k ? d[k] : iv;
+    return iv >= 0.0f ? cadd(cscale(c3p(sc.bg1), iv), cscale(c3p(sc.bg2), 1.0f - iv))
+                      : cadd(cscale(c3p(sc.bg3), -iv), cscale(c3p(sc.bg2), 1.0f + iv));
+}
+
+// base_color (tracer.hpp:1768-1854) for the scripted configuration: batches only, no lights, no reflective
+// material -- the camera light and its specular term.  Same operations, same order as composite_color.
+template <int N>
+__device__ __forceinline__ Color3 surface_color_lean(const NtCompositeDev &sc, const Hit &hit, const float (&o)[N], const float (&d)[N]) {
+    float no[N], nd[N];
+    hit_normal<N, false>(sc, hit, o, d, no, nd);
+    const float *m = material_of(sc, hit.item, hit.lane);
+    Color3 light = c3(0.0f, 0.0f, 0.0f), specular = c3(0.0f, 0.0f, 0.0f);
+    float spec_a = 0.0f;
+    const float sine = -dotN<N>(d, nd);
+    if (sc.camera_light && sine > 0.0f) {
+        light = cadd(light, c3(sine, sine, sine));
+        if (m[8] != 0.0f) {
+            const float base = powf(sine, m[9]) * m[8];
+            specular = cadd(specular, cscale(cscale(c3p(m + 3), base), (1.0f - spec_a)));
+            spec_a += base * (1.0f - spec_a);
+            specular = cscale(specular, spec_a);
+        }
+    }
+    const Color3 r0 = cadd(c3p(sc.ambient), cmul(c3p(m), light));
+    return cadd(specular, cscale(r0, 1.0f - spec_a));
+}
+
 template <int N, bool FEAT, bool STATS>
 __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, const WaveLds &w, int lane, float (&o)[N], float (&d)[N], Stats &st) {
     Level levels[FEAT ? NT_DEV_MAX_REFLECT : 1];
@@ -945,12 +1062,7 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
             found = trace_closest<N, FEAT, STATS>(sc, w, lane, o, d, dist, FLT_MAX, skip_item, skip_lane, hit, st);
         }
         if (!found) {
-            // target.direction[bg_gradient_axis]: select chain instead of indexing registers
-            float iv = d[0];
-#pragma unroll
-            for (int k = 1; k < N; ++k) iv = sc.bg_axis == k ? d[k] : iv;
-            result = iv >= 0.0f ? cadd(cscale(c3p(sc.bg1), iv), cscale(c3p(sc.bg2), 1.0f - iv))
-                                : cadd(cscale(c3p(sc.bg3), -iv), cscale(c3p(sc.bg2), 1.0f + iv));
+            result = background_color<N>(sc, d);
             break;
         }
         if (STATS && depth == 0) st.hits += 1;
@@ -1063,10 +1175,7 @@ __global__ __launch_bounds__(256) void composite_kernel(NtCameraFixed cam, NtCom
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wv = tid >> 6;
-    const int per_wave = (sc.stack_depth + N) * 64;
-    WaveLds w;
-    w.stack = lds_raw + (size_t)wv * per_wave;
-    w.ray = w.stack + (size_t)sc.stack_depth * 64;
+    const WaveLds w = wave_lds(reinterpret_cast<char *>(lds_raw), wv, sc.stack_depth, N);
 
     int px, py;
     if (tg.colors_out) { px = 0; py = 0; }
@@ -1087,6 +1196,445 @@ __global__ __launch_bounds__(256) void composite_kernel(NtCameraFixed cam, NtCom
         for (int k = 0; k < 8; ++k) {
             const unsigned int s = wave_sum(v[k]);
             if (lane == 0 && s) atomicAdd(sc.stats + k, (unsigned long long)s);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// Persistent variant of the lean composite kernel (batches only, camera light only: the scripted
+// configurations).  The k-d walk is the same as trace_closest, but every lane is a little state machine
+// and the wave alternates between
+//   phase A (cheap, divergent)   each lane advances -- branch steps, leaf entry, mailbox, pops -- until it
+//                                holds ONE pending batch to test or its ray is finished;
+//   phase B (expensive, converged) all lanes with a pending batch run the 4-simplex test together.
+// Lanes whose ray is finished shade + write their pixel and take the next pixel from a global counter
+// (one atomicAdd per wave: __ballot/__popcll rank), so a wave is not held hostage by its slowest ray:
+// leaf sizes range from 1 to ~1800 batches in the 120-cell and the per-tile variant runs at ~25 % lane use.
+// Pixels are numbered tile-major (8x8) so that refilled rays stay coherent.
+struct PersistArgs {
+    const float *cams;              // [frame][4][N]
+    unsigned long long *counter;    // zeroed by the host before the launch
+    long long total;                // frames * tiles_per_frame * 64
+    int tiles_x, tiles_per_frame;
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void composite_persistent(NtCompositeDev sc, NtTarget tg, PersistArgs pa) {
+    extern __shared__ float2 lds_raw[];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const WaveLds w = wave_lds(reinterpret_cast<char *>(lds_raw), wv, sc.stack_depth, N);
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int max_sp = sc.stack_depth;
+
+    // per-lane ray state
+    bool running = false;          // a ray is in flight in this lane
+    bool finished = false;         // ... and its traversal is complete (needs shading)
+    bool exhausted = false;        // the pixel pool is empty
+    long long out_off = 0;
+    float o[N], d[N];
+    Hit hit;
+    hit.dist = FLT_MAX; hit.item = -1; hit.lane = -1;
+    int node = -1, sp = 0, dirty = 0;
+    float t_near = 0.0f, t_far = FLT_MAX;
+    int leaf_pos = 0, leaf_end = 0;      // remaining items of the current leaf: [leaf_pos, leaf_end)
+    bool in_leaf = false, improved = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { o[k] = 0.0f; d[k] = 0.0f; }
+
+    for (;;) {
+        // ---------------- retire finished rays, refill idle lanes ----------------
+        const unsigned long long run_mask = __builtin_amdgcn_ballot_w64(running && !finished);
+        const int n_busy = (int)__popcll(run_mask);
+        if (n_busy <= 48) {              // refill when a quarter of the wave is idle (or nothing is running)
+            if (running && finished) {
+                const Color3 c = hit.item >= 0 ? surface_color_lean<N>(sc, hit, o, d) : background_color<N>(sc, d);
+                uint8_t *p = tg.dest + out_off;
+                // same epilogue as emit_pixel (image mode)
+                if (tg.pack_mode == NT_PACK_WORD32) {
+                    const uint32_t wd = pack_word32(c.r, c.g, c.b, tg);
+                    if (tg.bpp == 4 && tg.aligned4) *reinterpret_cast<uint32_t *>(p) = tg.reversed ? wd : bswap32(wd);
+                    else store_pixel(p, tg, (uint64_t)wd << 32, 0);
+                } else if (tg.pack_mode == NT_PACK_WORD64) {
+                    store_pixel(p, tg, pack_word64(c.r, c.g, c.b, tg), 0);
+                } else {
+                    uint64_t hi, lo;
+                    pack_pixel(c.r, c.g, c.b, tg, hi, lo);
+                    store_pixel(p, tg, hi, lo);
+                }
+                running = false;
+                finished = false;
+            }
+            // fetch until every idle lane has a ray that needs traversal, or the pool is empty
+            for (;;) {
+                const bool want = !running && !exhausted;
+                const unsigned long long want_mask = __builtin_amdgcn_ballot_w64(want);
+                if (want_mask == 0ull) break;
+                const int need = (int)__popcll(want_mask);
+                const int src = (int)__builtin_ctzll(want_mask);
+                unsigned long long base = 0;
+                if (lane == src) base = atomicAdd(pa.counter, (unsigned long long)need);
+                const unsigned int blo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(base & 0xffffffffull), src);
+                const unsigned int bhi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(base >> 32), src);
+                base = ((unsigned long long)bhi << 32) | blo;
+                if (want) {
+                    const long long id = (long long)base + (long long)__popcll(want_mask & lane_lt);
+                    if (id >= pa.total) {
+                        exhausted = true;
+                    } else {
+                        const int frame = (int)(id / ((long long)pa.tiles_per_frame * 64));
+                        const int rem = (int)(id - (long long)frame * pa.tiles_per_frame * 64);
+                        const int tile = rem >> 6, within = rem & 63;
+                        const int ty = tile / pa.tiles_x, tx = tile - ty * pa.tiles_x;
+                        const int x = tx * 8 + (within & 7);
+                        const int row = ty * 8 + (within >> 3);
+                        bool valid = x < tg.width && row < tg.row_count;
+                        int y = tg.row_begin + row;
+                        const int orow = y;
+                        if (valid && tg.band_world > 1) {
+                            const int band = orow / tg.band_rows;
+                            y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+                        }
+                        valid = valid && y < tg.height;
+                        if (valid) {
+                            out_off = (long long)frame * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+                            const float *c = pa.cams + (size_t)frame * 4 * N;
+                            float right[N], up[N], fwd[N];
+#pragma unroll
+                            for (int k = 0; k < N; ++k) { o[k] = c[k]; right[k] = c[N + k]; up[k] = c[2 * N + k]; fwd[k] = c[3 * N + k]; }
+                            primary_dir<N>(tg, right, up, fwd, x, y, d);
+                            running = true;
+                            finished = true;            // until the AABB test says otherwise
+                            hit.dist = FLT_MAX; hit.item = -1; hit.lane = -1;
+                            const float dist = aabb_distance<N>(sc, o, d);
+                            if (dist >= 0.0f) {
+                                setup_ray_table<N>(w, lane, o, d);
+                                mbox_reset(w, lane);
+                                node = sc.root; sp = 0; dirty = 0;
+                                t_near = dist; t_far = FLT_MAX;
+                                in_leaf = false; improved = false;
+                                finished = false;
+                            }
+                        }
+                    }
+                }
+                // rays that missed the scene box are shaded right away so their lanes can refill in this loop
+                if (running && finished) {
+                    const Color3 c = background_color<N>(sc, d);
+                    uint8_t *p = tg.dest + out_off;
+                    if (tg.pack_mode == NT_PACK_WORD32) {
+                        const uint32_t wd = pack_word32(c.r, c.g, c.b, tg);
+                        if (tg.bpp == 4 && tg.aligned4) *reinterpret_cast<uint32_t *>(p) = tg.reversed ? wd : bswap32(wd);
+                        else store_pixel(p, tg, (uint64_t)wd << 32, 0);
+                    } else if (tg.pack_mode == NT_PACK_WORD64) {
+                        store_pixel(p, tg, pack_word64(c.r, c.g, c.b, tg), 0);
+                    } else {
+                        uint64_t hi, lo;
+                        pack_pixel(c.r, c.g, c.b, tg, hi, lo);
+                        store_pixel(p, tg, hi, lo);
+                    }
+                    running = false;
+                    finished = false;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(running) == 0ull) break;     // pool empty and nothing in flight
+        }
+
+        // ---------------- phase A: advance to the next pending batch ----------------
+        int pending = -1;
+        while (running && !finished && pending < 0) {
+            if (in_leaf) {
+                if (leaf_pos < leaf_end) {
+                    const int item = sc.items[leaf_pos];
+                    ++leaf_pos;
+                    if (!mbox_seen(w, lane, item)) pending = item;
+                    continue;
+                }
+                in_leaf = false;
+                if (improved) dirty = sp;
+                node = -1;
+            }
+            if (node >= 0) {
+                const NtNode nd = sc.nodes[node];
+                if (nd.axis < 0) {
+                    in_leaf = true;
+                    improved = false;
+                    leaf_pos = nd.left;
+                    leaf_end = nd.left + nd.right;
+                    continue;
+                }
+                const float2 oi = w.ray[nd.axis * 64 + lane];
+                const float oa = oi.x, inv = oi.y;
+                if (inv == inv) {
+                    if (oa == nd.split) { node = inv > 0.0f ? nd.right : nd.left; continue; }
+                    const float t = (nd.split - oa) * inv;
+                    const bool gt = oa > nd.split;
+                    const int n_near = gt ? nd.right : nd.left;
+                    const int n_far = gt ? nd.left : nd.right;
+                    if (t < 0.0f || t > t_far) { node = n_near; continue; }
+                    if (t < t_near) { node = n_far; continue; }
+                    if (n_near >= 0) {
+                        if (sp < max_sp) { w.stack[sp * 64 + lane] = node; ++sp; }
+                        t_far = t;
+                        node = n_near;
+                        continue;
+                    }
+                    node = n_far;
+                    t_near = t;
+                    continue;
+                }
+                node = oa >= nd.split ? nd.right : nd.left;
+                continue;
+            }
+            // frame returned: pop
+            if (sp == 0) { finished = true; break; }
+            --sp;
+            const NtNode nd = sc.nodes[w.stack[sp * 64 + lane]];
+            bool gt;
+            const float t = branch_t(w, lane, nd, gt);
+            const int far = gt ? nd.left : nd.right;
+            const bool near_hit = sp < dirty;
+            if (dirty > sp) dirty = sp;
+            if ((near_hit && hit.dist <= t) || far < 0) continue;
+            node = far;
+            t_near = t;
+            t_far = FLT_MAX;
+            if (sp > 0) {
+                const NtNode up = sc.nodes[w.stack[(sp - 1) * 64 + lane]];
+                bool g2;
+                t_far = branch_t(w, lane, up, g2);
+            }
+        }
+
+        // ---------------- phase B: the batch test, lanes converged ----------------
+        if (pending >= 0) {
+            const int idx = pending >> 2;
+            float min_t = hit.dist;
+            int r = -1;
+            const float *base = sc.batch_recs + (size_t)idx * NT_DEV_BATCH * sc.rec_stride;
+#pragma unroll
+            for (int l = 0; l < NT_DEV_BATCH; ++l) {
+                SimplexRec<N> sr;
+                sr.load(base + (size_t)l * sc.rec_stride);
+                const float t = simplex_batch_form<N>(sr, o, d);
+                if (t != 0.0f && t < min_t) { min_t = t; r = l; }
+            }
+            if (r >= 0) { hit.dist = min_t; hit.item = pending; hit.lane = r; improved = true; }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// Packet variant of the lean composite kernel: one wave walks the k-d tree ONCE for its 8x8 tile of primary
+// rays.  Primary rays share the camera origin, so which child of a branch is "near" (tracer.hpp:1199-1200) is
+// the same for all 64 lanes; what differs per lane is only whether it enters near, far or both, and its
+// [t_near,t_far].  Control flow (node ids, leaf items) is therefore wave-uniform: node and simplex records
+// are fetched with scalar loads into SGPRs (no per-lane gathers through the vector memory pipe, which bound
+// the per-lane kernels), and every lane that the reference would take through a leaf tests the leaf's
+// batches in the reference's order.  Per lane the visited leaves, the cutoffs and hence the hit are those
+// of the per-lane walk (trace_closest); the frame stack holds, per level, the wave-uniform far node and lane
+// mask plus each lane's (t_split, t_far) pair.
+struct PacketArgs {
+    const float *cams;        // [frame][4][N]
+    int tiles_x;
+};
+
+// The per-lane part of the frame stack, (t_split | NaN = far-only, t_far to restore), lives in VGPRs: the
+// stack pointer is wave-uniform, so the arrays are indexed through M0 (s_set_gpr_idx), not spilled.  The ray's
+// origin / inverse direction are indexed the same way by the (uniform) split axis.  LDS only holds the
+// mailbox and the uniform (far node, lane mask) pairs, which keeps ~20 waves per CU resident.
+template <int N, int DEPTH>
+__global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarget tg, PacketArgs pa) {
+    extern __shared__ float2 lds_raw[];
+    const int lane = (int)threadIdx.x;
+    WaveLds w;              // view used by the shared helpers (mailbox only)
+    w.mbox = reinterpret_cast<int *>(lds_raw);
+    w.ray = nullptr;
+    w.stack = nullptr;
+    int *ustack = w.mbox + 64 * NT_MBOX;          // [DEPTH][4]: far node, mask lo, mask hi, -
+
+    // ---- this wave's tile
+    const int tile = (int)blockIdx.x;
+    const int ty = tile / pa.tiles_x, tx = tile - ty * pa.tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int row = ty * 8 + (lane >> 3);
+    bool valid = x < tg.width && row < tg.row_count;
+    const int orow = tg.row_begin + row;
+    int y = orow;
+    if (tg.band_world > 1) {
+        const int band = orow / tg.band_rows;
+        y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+    }
+    valid = valid && y < tg.height;
+    const long long out_off = (long long)blockIdx.y * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+
+    float o[N], d[N], invd[N];
+    {
+        const float *c = pa.cams + (size_t)blockIdx.y * 4 * N;
+        float right[N], up[N], fwd[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) { o[k] = c[k]; right[k] = c[N + k]; up[k] = c[2 * N + k]; fwd[k] = c[3 * N + k]; }
+        primary_dir<N>(tg, right, up, fwd, x, y, d);
+        // invdir = 1/direction (tracer.hpp:1174); NaN marks direction == 0 (see setup_ray_table)
+#pragma unroll
+        for (int k = 0; k < N; ++k) invd[k] = d[k] != 0.0f ? 1.0f / d[k] : __int_as_float(0x7fc00000);
+    }
+    Hit hit;
+    hit.dist = FLT_MAX; hit.item = -1; hit.lane = -1;
+    const float dist0 = aabb_distance<N>(sc, o, d);
+    bool active = valid && dist0 >= 0.0f;
+    float t_near = dist0, t_far = FLT_MAX;
+    int dirty = 0;
+    float st_t[DEPTH], st_f[DEPTH];
+    mbox_reset(w, lane);
+
+    int node = sc.root;      // wave-uniform
+    int sp = 0;              // wave-uniform
+    for (;;) {
+        while (node >= 0) {
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) { node = -1; break; }
+            const NtNode nd = sc.nodes[node];                // uniform address -> scalar load
+            if (nd.axis < 0) {
+                // ---- leaf: kd_leaf<Store,true>::intersects (tracer.hpp:977-1086), batches only
+                bool improved = false;
+                for (int i = 0; i < nd.right; ++i) {
+                    const int item = __builtin_amdgcn_readfirstlane(sc.items[nd.left + i]);
+                    bool doit = false;
+                    if (active) doit = !mbox_seen(w, lane, item);
+                    if (__builtin_amdgcn_ballot_w64(doit) == 0ull) continue;
+                    const float *base = sc.batch_recs + (size_t)(item >> 2) * NT_DEV_BATCH * sc.rec_stride;
+                    // stage 1 for the 4 simplices at once: only d, face_normal, p1 (9 + N-4.. floats) are fetched,
+                    // so all plane tests share one scalar-memory round trip
+                    float tl[NT_DEV_BATCH];
+                    bool ok1[NT_DEV_BATCH];
+#pragma unroll
+                    for (int l = 0; l < NT_DEV_BATCH; ++l) {
+                        const float *rec = base + (size_t)l * sc.rec_stride;
+                        float denom = rec[1] * d[0];
+#pragma unroll
+                        for (int k = 1; k < N; ++k) denom = denom + rec[1 + k] * d[k];
+                        float no = rec[1] * o[0];
+#pragma unroll
+                        for (int k = 1; k < N; ++k) no = no + rec[1 + k] * o[k];
+                        tl[l] = -(no + rec[0]) / denom;
+                        ok1[l] = denom != 0.0f && tl[l] >= 0.0f;
+                    }
+                    float min_t = hit.dist;
+                    int r = -1;
+#pragma unroll
+                    for (int l = 0; l < NT_DEV_BATCH; ++l) {
+                        // stage 2 only if some lane can still accept this simplex (same accept rule as below)
+                        const float t = tl[l];
+                        if (__builtin_amdgcn_ballot_w64(doit && ok1[l] && t != 0.0f && t < min_t) == 0ull) continue;
+                        const float *rec = base + (size_t)l * sc.rec_stride;
+                        float pside[N];
+#pragma unroll
+                        for (int k = 0; k < N; ++k) pside[k] = rec[1 + N + k] - (o[k] + t * d[k]);
+                        bool ok = ok1[l];
+                        float tot = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < N - 1; ++e) {
+                            const float *en = rec + 1 + 2 * N + e * N;
+                            float area = en[0] * pside[0];
+#pragma unroll
+                            for (int k = 1; k < N; ++k) area = area + en[k] * pside[k];
+                            ok = ok && area >= -NT_FUZZ;
+                            tot += area;
+                        }
+                        ok = ok && tot <= (1.0f + NT_FUZZ);
+                        if (ok && t != 0.0f && t < min_t) { min_t = t; r = l; }
+                    }
+                    if (doit && r >= 0) { hit.dist = min_t; hit.item = item; hit.lane = r; improved = true; }
+                }
+                if (improved) dirty = sp;
+                node = -1;
+                break;
+            }
+            // ---- branch: kd_node_intersection::operator() (tracer.hpp:1189-1240)
+            const int axis = nd.axis;                          // uniform -> M0-indexed register reads
+            const float oa = o[axis], inv = invd[axis];        // oa is the same in every lane (shared origin)
+            const bool gt = __builtin_amdgcn_readfirstlane((int)(oa > nd.split)) != 0;
+            const int n_near = gt ? nd.right : nd.left;
+            const int n_far = gt ? nd.left : nd.right;
+            bool go_near = false, go_far = false, both = false;
+            float t = 0.0f;
+            if (active) {
+                if (inv == inv) {
+                    if (oa == nd.split) {
+                        // node = direction > 0 ? right : left; with oa == split: near = left, far = right
+                        if (inv > 0.0f) go_far = true; else go_near = true;
+                    } else {
+                        t = (nd.split - oa) * inv;
+                        if (t < 0.0f || t > t_far) go_near = true;
+                        else if (t < t_near) go_far = true;
+                        else both = true;
+                    }
+                } else {
+                    // direction[axis] == 0: node = origin >= split ? right : left
+                    const bool to_right = oa >= nd.split;
+                    if (to_right == gt) go_near = true; else go_far = true;       // near == right iff gt
+                }
+            }
+            // a `both` lane with no near child continues in far with t_near = t (tracer.hpp:1234-1237);
+            // with no far child it returns after near (:1214)
+            const bool near_lane = (go_near || both) && n_near >= 0;
+            const bool far_after = (go_far || both) && n_far >= 0 && n_near >= 0;      // far AFTER a near subtree
+            const unsigned long long m_near = __builtin_amdgcn_ballot_w64(near_lane);
+            const unsigned long long m_far = __builtin_amdgcn_ballot_w64(far_after);
+            if (m_near != 0ull) {
+                if (m_far != 0ull && sp < DEPTH) {
+                    if (lane == 0) {
+                        ustack[sp * 4 + 0] = n_far;
+                        ustack[sp * 4 + 1] = (int)(unsigned int)(m_far & 0xffffffffull);
+                        ustack[sp * 4 + 2] = (int)(unsigned int)(m_far >> 32);
+                    }
+                    st_t[sp] = both ? t : __int_as_float(0x7fc00000);
+                    st_f[sp] = t_far;
+                    ++sp;
+                }
+                if (both && near_lane) t_far = t;
+                active = near_lane;
+                node = n_near;
+            } else {
+                // no lane enters near: lanes bound for far go there now
+                const bool goes = (go_far || both) && n_far >= 0;
+                if (both && goes) t_near = t;
+                active = goes;
+                node = __builtin_amdgcn_ballot_w64(goes) != 0ull ? n_far : -1;
+            }
+        }
+        // ---- the frame returned: resume the innermost pending far side
+        if (sp == 0) break;
+        --sp;
+        const int far = __builtin_amdgcn_readfirstlane(ustack[sp * 4 + 0]);
+        const unsigned long long m = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 4 + 2]) << 32) |
+                                     (unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 4 + 1]);
+        const float et = st_t[sp], ef = st_f[sp];
+        const bool near_hit = sp < dirty;
+        if (dirty > sp) dirty = sp;
+        bool join = ((m >> lane) & 1ull) != 0ull;
+        if (join && et == et) {                            // a `both` lane: (hit && o_hit.dist <= t) -> return
+            if (near_hit && hit.dist <= et) join = false;
+            else { t_near = et; t_far = ef; }
+        }
+        active = join;
+        node = far;
+    }
+
+    if (valid) {
+        const Color3 c = hit.item >= 0 ? surface_color_lean<N>(sc, hit, o, d) : background_color<N>(sc, d);
+        uint8_t *p = tg.dest + out_off;
+        if (tg.pack_mode == NT_PACK_WORD32) {
+            const uint32_t wd = pack_word32(c.r, c.g, c.b, tg);
+            if (tg.bpp == 4 && tg.aligned4) *reinterpret_cast<uint32_t *>(p) = tg.reversed ? wd : bswap32(wd);
+            else store_pixel(p, tg, (uint64_t)wd << 32, 0);
+        } else if (tg.pack_mode == NT_PACK_WORD64) {
+            store_pixel(p, tg, pack_word64(c.r, c.g, c.b, tg), 0);
+        } else {
+            uint64_t hi, lo;
+            pack_pixel(c.r, c.g, c.b, tg, hi, lo);
+            store_pixel(p, tg, hi, lo);
         }
     }
 }
@@ -1124,13 +1672,48 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];
     dim3 grid;
     grid_for(tg, 16, 16, li.nframes, grid);
-    const size_t lds = (size_t)4 * (sc.stack_depth + N) * 64 * sizeof(float2);
+    const size_t lds = (size_t)4 * 64 * ((size_t)sc.stack_depth * 4 + (size_t)N * 8 + (size_t)NT_MBOX * 4);
     if (lds > 160 * 1024) {
         snprintf(g_launch_error, sizeof(g_launch_error), "k-d tree too deep for the LDS traversal stack (depth %d)", sc.stack_depth);
         return -1;
     }
     const bool feat = sc.n_point_lights || sc.n_global_lights || sc.any_reflective || sc.has_scalar_prims;
     hipStream_t s = (hipStream_t)li.stream;
+    if (!feat && !sc.stats && !tg.colors_out && li.persist_cams && li.kernel_choice != 1 && sc.stack_depth <= 32) {
+        // packet kernel: one wave per 8x8 tile, wave-uniform tree walk
+        PacketArgs pk;
+        pk.cams = li.persist_cams;
+        pk.tiles_x = (tg.width + 7) / 8;
+        const int tiles = pk.tiles_x * ((tg.row_count + 7) / 8);
+        const dim3 pgrid((unsigned)tiles, (unsigned)li.nframes);
+        if (sc.stack_depth <= 16) {
+            const size_t plds = (size_t)64 * NT_MBOX * 4 + (size_t)16 * 16;
+            hipLaunchKernelGGL((composite_packet<N, 16>), pgrid, dim3(64), plds, s, sc, tg, pk);
+        } else {
+            const size_t plds = (size_t)64 * NT_MBOX * 4 + (size_t)32 * 16;
+            hipLaunchKernelGGL((composite_packet<N, 32>), pgrid, dim3(64), plds, s, sc, tg, pk);
+        }
+        return 0;
+    }
+    if (!feat && !sc.stats && !tg.colors_out && li.persist_counter) {
+        // persistent waves + ray refill
+        PersistArgs pa;
+        pa.cams = li.persist_cams;
+        pa.counter = (unsigned long long *)li.persist_counter;
+        pa.tiles_x = (tg.width + 7) / 8;
+        pa.tiles_per_frame = pa.tiles_x * ((tg.row_count + 7) / 8);
+        pa.total = (long long)li.nframes * pa.tiles_per_frame * 64;
+        const size_t lds_block = lds;
+        int blocks_per_cu = (int)(160 * 1024 / lds_block);
+        if (blocks_per_cu > 8) blocks_per_cu = 8;
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+        long long want_blocks = (pa.total + 255) / 256;
+        int nblocks = li.cu_count * blocks_per_cu;
+        if ((long long)nblocks > want_blocks) nblocks = (int)want_blocks;
+        if (nblocks < 1) nblocks = 1;
+        hipLaunchKernelGGL((composite_persistent<N>), dim3((unsigned)nblocks), dim3(256), lds, s, sc, tg, pa);
+        return 0;
+    }
     if (sc.stats) hipLaunchKernelGGL((composite_kernel<N, true, true>), grid, dim3(256), lds, s, cf, sc, tg);
     else if (feat) hipLaunchKernelGGL((composite_kernel<N, true, false>), grid, dim3(256), lds, s, cf, sc, tg);
     else hipLaunchKernelGGL((composite_kernel<N, false, false>), grid, dim3(256), lds, s, cf, sc, tg);
