@@ -343,7 +343,9 @@ void fill_composite(const nt_scene *s, const DeviceState *ds, NtCompositeDev &c,
 int check_renderable(const nt_scene *s) {
     if (s->composite) {
         if (s->n > NT_MAX_FIXED_DIM) return fail(NT_E_UNSUPPORTED, "composite scenes are implemented for dimensions 3..%d (got %d)", NT_MAX_FIXED_DIM, s->n);
-        if (!s->all_opaque) return fail(NT_E_UNSUPPORTED, "transparent materials (opacity < 1) are not implemented on the GPU path yet");
+        if (!s->all_opaque && s->any_reflective && s->max_reflect_depth > 5)
+            return fail(NT_E_UNSUPPORTED, "max_reflect_depth > 5 is not supported for scenes with transparent materials");
+        if (s->nodes.size() >= (1u << 24)) return fail(NT_E_UNSUPPORTED, "k-d trees with 2^24 or more nodes are not supported");
         if (s->max_reflect_depth > NT_DEV_MAX_REFLECT && s->any_reflective)
             return fail(NT_E_UNSUPPORTED, "max_reflect_depth > %d is not supported", NT_DEV_MAX_REFLECT);
     }

@@ -1161,6 +1161,497 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
     return result;
 }
 
+// --------------------------------------------------------------------------------------
+// Transparent materials (opacity < 1): the general ray_color / base_color recursion
+// (tracer.hpp:1768-1883) with transparent-hit lists, run as an explicit frame stack.
+// Slow path: lists and frames live in per-lane scratch memory.  Normals follow the "clean"
+// semantics documented in DESIGN.md (a hit's normal is that of the primitive that was hit).
+// --------------------------------------------------------------------------------------
+#define NT_TH_MAX 24        // transparent hits kept per ray (the reference misbehaves beyond 10)
+#define NT_TFRAMES 6        // ray_color frames: max_reflect_depth <= 5 when transparency is present
+#define NT_STK_MARK 0x80000000u
+
+struct THit {
+    float dist;
+    int item;
+    int lane;
+};
+
+struct TList {
+    THit e[NT_TH_MAX];
+    int n;
+};
+
+__device__ __forceinline__ void tl_add(TList &l, float dist, int item, int lane) {
+    if (l.n < NT_TH_MAX) {
+        l.e[l.n].dist = dist;
+        l.e[l.n].item = item;
+        l.e[l.n].lane = lane;
+        ++l.n;
+    }
+}
+
+// trim_intersections (tracer.hpp:784-789) with quick_list::remove_at's swap-with-last (:723-728)
+__device__ __forceinline__ void tl_trim(TList &l, float dist, int from) {
+    while (from < l.n) {
+        if (l.e[from].dist >= dist) {
+            --l.n;
+            if (from != l.n) l.e[from] = l.e[l.n];
+        } else {
+            ++from;
+        }
+    }
+}
+
+// sort_and_unique (tracer.hpp:714-721): ascending dist, adjacent equal targets collapsed
+__device__ __forceinline__ void tl_sort_unique(TList &l) {
+    for (int i = 1; i < l.n; ++i) {
+        const THit x = l.e[i];
+        int j = i - 1;
+        while (j >= 0 && l.e[j].dist > x.dist) { l.e[j + 1] = l.e[j]; --j; }
+        l.e[j + 1] = x;
+    }
+    int w = 0;
+    for (int i = 0; i < l.n; ++i) {
+        if (w == 0 || !(l.e[w - 1].item == l.e[i].item && l.e[w - 1].lane == l.e[i].lane)) {
+            if (w != i) l.e[w] = l.e[i];
+            ++w;
+        }
+    }
+    l.n = w;
+}
+
+// one primitive test for the transparent path: returns t (0 = miss) and the batch lane
+template <int N>
+__device__ __forceinline__ float test_item(const NtCompositeDev &sc, int item, const float (&o)[N], const float (&d)[N], float cutoff,
+                                           int skip_item, int skip_lane, int &lane_out) {
+    const int kind = item & 3, idx = item >> 2;
+    lane_out = -1;
+    if (kind == 0) {
+        const int sl = item == skip_item ? skip_lane : -1;
+        float min_t = cutoff;
+        int r = -1;
+        const float *base = sc.batch_recs + (size_t)idx * NT_DEV_BATCH * sc.rec_stride;
+#pragma unroll
+        for (int l = 0; l < NT_DEV_BATCH; ++l) {
+            SimplexRec<N> s;
+            s.load(base + (size_t)l * sc.rec_stride);
+            const float t = simplex_batch_form<N>(s, o, d);
+            if (l != sl && t != 0.0f && t < min_t) { min_t = t; r = l; }
+        }
+        lane_out = r;
+        return r >= 0 ? min_t : 0.0f;
+    }
+    if (kind == 1) {
+        SimplexRec<N> s;
+        s.load(sc.tri_recs + (size_t)idx * sc.rec_stride);
+        return simplex_scalar_form<N>(s, o, d, cutoff);
+    }
+    float no[N], nd[N];
+    return solid_intersects<N>(sc, idx, o, d, cutoff, false, no, nd);
+}
+
+// kd_leaf<Store,true>::intersects (tracer.hpp:977-1086) with transparent hits: first loop until an opaque
+// hit, then "is there anything closer?", then trim_intersections with the LAST test's dist (:1084).
+template <int N>
+__device__ __noinline__ bool leaf_closest_t(const NtCompositeDev &sc, const WaveLds &w, int lane, int start, int count, const float (&o)[N],
+                                            const float (&d)[N], int skip_item, int skip_lane, Hit &hit, TList &th) {
+    const int h_start = th.n;
+    bool found = false;
+    float dist_last = 0.0f;
+    for (int i = 0; i < count; ++i) {
+        const int item = sc.items[start + i];
+        if ((item & 3) != 0 && item == skip_item) continue;
+        if (mbox_seen(w, lane, item)) continue;
+        int l;
+        const float t = test_item<N>(sc, item, o, d, hit.dist, skip_item, skip_lane, l);
+        dist_last = t;
+        if (t != 0.0f) {
+            if (material_of(sc, item, l)[6] >= 1.0f) {
+                hit.dist = t;
+                hit.item = item;
+                hit.lane = l;
+                if (!found) {           // `goto hit`: the item is re-tested against its own distance and misses
+                    found = true;
+                    dist_last = 0.0f;
+                }
+            } else {
+                tl_add(th, t, item, l);
+            }
+        }
+    }
+    if (found) tl_trim(th, dist_last, h_start);
+    return found;
+}
+
+// kd_node_intersection::operator() with the transparent-list trims (tracer.hpp:1211-1231).  Stack entries:
+// branch index | list size at the push << 24; NT_STK_MARK marks "far side of this branch is being walked
+// after a near hit: trim the list when it returns with a closer hit".
+template <int N>
+__device__ __noinline__ bool trace_closest_t(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
+                                             float t_near, int skip_item, int skip_lane, Hit &hit, TList &th) {
+    hit.dist = FLT_MAX;
+    hit.item = -1;
+    hit.lane = -1;
+    th.n = 0;
+    mbox_reset(w, lane);
+    int node = sc.root;
+    int sp = 0;
+    int dirty = 0;
+    float t_far = FLT_MAX;
+    const int max_sp = sc.stack_depth;
+    for (;;) {
+        while (node >= 0) {
+            const NtNode nd = sc.nodes[node];
+            if (nd.axis < 0) {
+                if (leaf_closest_t<N>(sc, w, lane, nd.left, nd.right, o, d, skip_item, skip_lane, hit, th)) dirty = sp;
+                node = -1;
+                break;
+            }
+            const float2 oi = w.ray[nd.axis * 64 + lane];
+            const float oa = oi.x, inv = oi.y;
+            if (inv == inv) {
+                if (oa == nd.split) { node = inv > 0.0f ? nd.right : nd.left; continue; }
+                const float t = (nd.split - oa) * inv;
+                const bool gt = oa > nd.split;
+                const int n_near = gt ? nd.right : nd.left;
+                const int n_far = gt ? nd.left : nd.right;
+                if (t < 0.0f || t > t_far) { node = n_near; continue; }
+                if (t < t_near) { node = n_far; continue; }
+                if (n_near >= 0) {
+                    if (sp < max_sp) {
+                        w.stack[sp * 64 + lane] = (int)((unsigned)node | ((unsigned)th.n << 24));
+                        ++sp;
+                    }
+                    t_far = t;
+                    node = n_near;
+                    continue;
+                }
+                node = n_far;
+                t_near = t;
+                continue;
+            }
+            node = oa >= nd.split ? nd.right : nd.left;
+        }
+        bool resumed = false;
+        while (sp > 0) {
+            --sp;
+            const unsigned e = (unsigned)w.stack[sp * 64 + lane];
+            const bool improved = sp < dirty;
+            if (dirty > sp) dirty = sp;
+            const int h_start = (int)((e >> 24) & 0x7fu);
+            if (e & NT_STK_MARK) {
+                // the far call of tracer.hpp:1225 has returned
+                if (improved) tl_trim(th, hit.dist, h_start);
+                continue;                                           // return true
+            }
+            const NtNode nd = sc.nodes[e & 0xffffffu];
+            bool gt;
+            const float t = branch_t(w, lane, nd, gt);
+            const int far = gt ? nd.left : nd.right;
+            if ((improved && hit.dist <= t) || far < 0) continue;   // return hit
+            if (improved) {                                         // near hit beyond the split: walk far, then trim
+                w.stack[sp * 64 + lane] = (int)(e | NT_STK_MARK);
+                ++sp;
+            }
+            node = far;
+            t_near = t;
+            // t_far of this frame: the split of the nearest pending (non-marker) branch below
+            t_far = FLT_MAX;
+            for (int k = (improved ? sp - 2 : sp - 1); k >= 0; --k) {
+                const unsigned ek = (unsigned)w.stack[k * 64 + lane];
+                if (!(ek & NT_STK_MARK)) {
+                    const NtNode up = sc.nodes[ek & 0xffffffu];
+                    bool g2;
+                    t_far = branch_t(w, lane, up, g2);
+                    break;
+                }
+            }
+            resumed = true;
+            break;
+        }
+        if (!resumed) break;
+    }
+    return hit.item >= 0;
+}
+
+// _occludes + kd_leaf::occludes with transparent hits collected (tracer.hpp:1088-1124, 1258-1307)
+template <int N>
+__device__ __noinline__ bool trace_occluded_t(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
+                                              float ldistance, int skip_item, int skip_lane, TList &sh) {
+    setup_ray_table<N>(w, lane, o, d);
+    sh.n = 0;
+    int node = sc.root;
+    int sp = 0;
+    float t_near = 0.0f;
+    float t_far = FLT_MAX;
+    const int max_sp = sc.stack_depth;
+    for (;;) {
+        while (node >= 0) {
+            const NtNode nd = sc.nodes[node];
+            if (nd.axis < 0) {
+                for (int i = 0; i < nd.right; ++i) {
+                    const int item = sc.items[nd.left + i];
+                    if ((item & 3) != 0 && item == skip_item) continue;
+                    int l;
+                    const float t = test_item<N>(sc, item, o, d, ldistance, skip_item, skip_lane, l);
+                    if (t != 0.0f) {
+                        if (material_of(sc, item, l)[6] >= 1.0f) return true;
+                        tl_add(sh, t, item, l);
+                    }
+                }
+                node = -1;
+                break;
+            }
+            const float2 oi = w.ray[nd.axis * 64 + lane];
+            const float oa = oi.x, inv = oi.y;
+            if (inv == inv) {
+                if (oa == nd.split) { node = inv > 0.0f ? nd.right : nd.left; continue; }
+                const float t = (nd.split - oa) * inv;
+                const bool gt = oa > nd.split;
+                const int n_near = gt ? nd.right : nd.left;
+                const int n_far = gt ? nd.left : nd.right;
+                if (t < 0.0f || t > t_far) { node = n_near; continue; }
+                if (t < t_near) { node = n_far; continue; }
+                if (n_near >= 0) {
+                    if (sp < max_sp) { w.stack[sp * 64 + lane] = node; ++sp; }
+                    t_far = t;
+                    node = n_near;
+                    continue;
+                }
+                if (t < ldistance) { node = -1; break; }
+                t_near = t;
+                node = n_far;
+                continue;
+            }
+            node = oa >= nd.split ? nd.right : nd.left;
+        }
+        bool resumed = false;
+        while (sp > 0) {
+            --sp;
+            const NtNode nd = sc.nodes[w.stack[sp * 64 + lane]];
+            bool gt;
+            const float t = branch_t(w, lane, nd, gt);
+            const int far = gt ? nd.left : nd.right;
+            if (t < ldistance || far < 0) continue;
+            node = far;
+            t_near = t;
+            t_far = FLT_MAX;
+            if (sp > 0) {
+                const NtNode up = sc.nodes[w.stack[(sp - 1) * 64 + lane]];
+                bool g2;
+                t_far = branch_t(w, lane, up, g2);
+            }
+            resumed = true;
+            break;
+        }
+        if (!resumed) return false;
+    }
+}
+
+// light_reaches (tracer.hpp:1750-1766)
+template <int N>
+__device__ __forceinline__ bool light_reaches_t(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
+                                                float ldistance, int skip_item, int skip_lane, Color3 &filtered) {
+    TList sh;
+    if (trace_occluded_t<N>(sc, w, lane, o, d, ldistance, skip_item, skip_lane, sh)) return false;
+    if (sh.n) {
+        tl_sort_unique(sh);
+        for (int i = sh.n - 1; i >= 0; --i) filtered = cscale(filtered, 1.0f - material_of(sc, sh.e[i].item, sh.e[i].lane)[6]);
+    }
+    return true;
+}
+
+template <int N>
+struct TFrame {
+    float o[N], d[N];
+    int depth, skip_item, skip_lane;
+    int nsurf, j;                 // surfaces: [0] = opaque hit (item < 0: background), then transparent hits far -> near
+    THit surf[NT_TH_MAX + 1];
+    Color3 r;                     // colour composited so far
+    Color3 spec, r0, c;           // base_color of surface j, waiting for its reflection
+    float spec_a, refl;
+};
+
+template <int N>
+__device__ __noinline__ Color3 composite_color_t(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&org)[N], const float (&dir)[N]) {
+    TFrame<N> frames[NT_TFRAMES];
+    int fp = 0;
+    {
+        TFrame<N> &F = frames[0];
+#pragma unroll
+        for (int k = 0; k < N; ++k) { F.o[k] = org[k]; F.d[k] = dir[k]; }
+        F.depth = 0;
+        F.skip_item = -1;
+        F.skip_lane = -1;
+    }
+    int state = 0;          // 0: trace the frame's ray, 1: shade its next surface, 2: a reflection has returned
+    Color3 result = c3(0.0f, 0.0f, 0.0f);
+    for (;;) {
+        TFrame<N> &F = frames[fp];
+        if (state == 0) {
+            // ---- ray_color: intersect (tracer.hpp:1861-1868)
+            float o[N], d[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) { o[k] = F.o[k]; d[k] = F.d[k]; }
+            TList th;
+            th.n = 0;
+            Hit hit;
+            hit.item = -1; hit.lane = -1; hit.dist = FLT_MAX;
+            const float dist = aabb_distance<N>(sc, o, d);
+            if (dist >= 0.0f) {
+                setup_ray_table<N>(w, lane, o, d);
+                trace_closest_t<N>(sc, w, lane, o, d, dist, F.skip_item, F.skip_lane, hit, th);
+            }
+            tl_sort_unique(th);
+            F.surf[0].dist = hit.dist;
+            F.surf[0].item = hit.item;
+            F.surf[0].lane = hit.lane;
+            for (int i = 0; i < th.n; ++i) F.surf[1 + i] = th.e[th.n - 1 - i];      // farthest first (:1874)
+            F.nsurf = 1 + th.n;
+            F.j = 0;
+            F.r = c3(0.0f, 0.0f, 0.0f);
+            state = 1;
+            continue;
+        }
+        float o[N], d[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) { o[k] = F.o[k]; d[k] = F.d[k]; }
+        Color3 col;
+        float opacity = 1.0f;
+        if (state == 1) {
+            if (F.j == F.nsurf) {
+                // ---- the frame is complete: hand its colour to the waiting base_color, or finish
+                result = F.r;
+                if (fp == 0) break;
+                --fp;
+                state = 2;
+                continue;
+            }
+            const THit sf = F.surf[F.j];
+            if (sf.item < 0) {            // miss: background (only surface 0 can be this)
+                F.r = background_color<N>(sc, d);
+                ++F.j;
+                continue;
+            }
+            // ---- base_color (tracer.hpp:1768-1854)
+            Hit hit;
+            hit.dist = sf.dist; hit.item = sf.item; hit.lane = sf.lane;
+            float no[N], nd[N];
+            hit_normal<N, true>(sc, hit, o, d, no, nd);
+            const float *m = material_of(sc, hit.item, hit.lane);
+            opacity = m[6];
+            Color3 light = c3(0.0f, 0.0f, 0.0f), specular = c3(0.0f, 0.0f, 0.0f);
+            float spec_a = 0.0f;
+            for (int li = 0; li < sc.n_point_lights; ++li) {
+                const float *pos = sc.pl_pos + (size_t)li * N;
+                const Color3 plc = c3p(sc.pl_color + 3 * li);
+                float lv[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) lv[k] = no[k] - pos[k];
+                const float ldist = sqrtf(dotN<N>(lv, lv));
+#pragma unroll
+                for (int k = 0; k < N; ++k) lv[k] = lv[k] / ldist;
+                const float sine = dotN<N>(nd, lv);
+                if (sine > 0.0f) {
+                    const float strength = (float)(1.0 / pow((double)ldist, (double)(N - 1)));
+                    if (sc.shadows) {
+                        if (fmaxf(plc.r, fmaxf(plc.g, plc.b)) * strength * sine > NT_LIGHT_THRESHOLD) {
+                            Color3 filtered = plc;
+                            if (light_reaches_t<N>(sc, w, lane, no, lv, ldist, hit.item, hit.lane, filtered)) {
+                                filtered = cscale(filtered, strength);
+                                light = cadd(light, cscale(filtered, sine));
+                                if (m[8] != 0.0f) append_specular<N>(specular, spec_a, m, filtered, d, nd, lv);
+                            }
+                        }
+                    } else {
+                        light = cadd(light, cscale(cscale(plc, strength), sine));
+                    }
+                }
+            }
+            for (int li = 0; li < sc.n_global_lights; ++li) {
+                const float *gd = sc.gl_dir + (size_t)li * N;
+                const Color3 glc = c3p(sc.gl_color + 3 * li);
+                float gdir[N], neg[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) { gdir[k] = gd[k]; neg[k] = -gd[k]; }
+                const float sine = -dotN<N>(nd, gdir);
+                if (sine > 0.0f) {
+                    if (sc.shadows) {
+                        Color3 filtered = glc;
+                        if (light_reaches_t<N>(sc, w, lane, no, neg, FLT_MAX, hit.item, hit.lane, filtered)) {
+                            light = cadd(light, cscale(filtered, sine));
+                            if (m[8] != 0.0f) append_specular<N>(specular, spec_a, m, filtered, d, nd, neg);
+                        }
+                    } else {
+                        light = cadd(light, cscale(glc, sine));
+                    }
+                }
+            }
+            const float sine = -dotN<N>(d, nd);
+            if (sc.camera_light && sine > 0.0f) {
+                light = cadd(light, c3(sine, sine, sine));
+                if (m[8] != 0.0f) {
+                    const float base = powf(sine, m[9]) * m[8];
+                    specular = cadd(specular, cscale(cscale(c3p(m + 3), base), (1.0f - spec_a)));
+                    spec_a += base * (1.0f - spec_a);
+                    specular = cscale(specular, spec_a);
+                }
+            }
+            const Color3 r0 = cadd(c3p(sc.ambient), cmul(c3p(m), light));
+            if (m[7] != 0.0f && F.depth < sc.max_reflect_depth && fp + 1 < NT_TFRAMES) {
+                F.spec = specular;
+                F.spec_a = spec_a;
+                F.r0 = r0;
+                F.c = c3p(m);
+                F.refl = m[7];
+                TFrame<N> &G = frames[fp + 1];
+                const float f = -2.0f * sine;
+#pragma unroll
+                for (int k = 0; k < N; ++k) { G.d[k] = d[k] - nd[k] * f; G.o[k] = no[k]; }
+                G.depth = F.depth + 1;
+                G.skip_item = hit.item;
+                G.skip_lane = hit.lane;
+                ++fp;
+                state = 0;
+                continue;
+            }
+            col = cadd(specular, cscale(r0, 1.0f - spec_a));
+        } else {
+            // ---- state 2: the reflection of surface j returned `result` (tracer.hpp:1842-1853)
+            const Color3 r = cadd(cscale(cmul(F.c, result), F.refl), cscale(F.r0, 1.0f - F.refl));
+            col = cadd(F.spec, cscale(r, 1.0f - F.spec_a));
+            opacity = material_of(sc, F.surf[F.j].item, F.surf[F.j].lane)[6];
+            state = 1;
+        }
+        // ---- ray_color: the opaque hit is the base, transparent hits are blended over it (:1864, :1878)
+        if (F.j == 0) F.r = col;
+        else F.r = cadd(cscale(col, opacity), cscale(F.r, 1.0f - opacity));
+        ++F.j;
+    }
+    return result;
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void composite_kernel_t(NtCameraFixed cam, NtCompositeDev sc, NtTarget tg) {
+    extern __shared__ float2 lds_raw[];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const WaveLds w = wave_lds(reinterpret_cast<char *>(lds_raw), wv, sc.stack_depth, N);
+    int px, py;
+    if (tg.colors_out) { px = 0; py = 0; }
+    else { px = (wv & 1) * 8 + (lane & 7); py = (wv >> 1) * 8 + (lane >> 3); }
+    const PixelRef pr = locate_pixel<16, 16>(tg, px, py, tid);
+    if (pr.valid) {
+        float org[N], right[N], up[N], fwd[N], dir[N];
+        load_camera<N>(cam, org, right, up, fwd);
+        primary_dir<N>(tg, right, up, fwd, pr.x, pr.y, dir);
+        const Color3 c = composite_color_t<N>(sc, w, lane, org, dir);
+        emit_pixel(tg, pr, c.r, c.g, c.b);
+    }
+}
+
 __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -1679,6 +2170,10 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
     }
     const bool feat = sc.n_point_lights || sc.n_global_lights || sc.any_reflective || sc.has_scalar_prims;
     hipStream_t s = (hipStream_t)li.stream;
+    if (!sc.all_opaque) {
+        hipLaunchKernelGGL((composite_kernel_t<N>), grid, dim3(256), lds, s, cf, sc, tg);
+        return 0;
+    }
     if (!feat && !sc.stats && !tg.colors_out && li.persist_cams && li.kernel_choice != 1 && sc.stack_depth <= 32) {
         // packet kernel: one wave per 8x8 tile, wave-uniform tree walk
         PacketArgs pk;

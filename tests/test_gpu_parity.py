@@ -264,6 +264,32 @@ def test_lights_shadows_reflection_solids_vs_oracle():
         assert np.abs(c - o).max() < TOL_ORACLE, str(v)
 
 
+def test_transparency_vs_oracle():
+    """The full feature scene: transparent and transparent+reflective materials on top of everything above --
+    transparent-hit lists with the reference's trims (tracer.hpp:1084,1228), back-to-front compositing
+    (:1870-1880), shadow filtering through transparent blockers (:1755-1763), reflection off transparent
+    surfaces.  Oracle in clean-normal mode."""
+    g = fx.load("feature3d")
+    flat = fx.flat_of(g)
+    w, h = int(g["width"]), int(g["height"])
+    ys, xs = np.mgrid[0:h, 0:w]
+    sc = tracern.CompositeScene.from_flat(3, flat)
+    sc._set_camera_arrays(g["origin"], g["axes"])
+    for v in g["variants"]:
+        p = fx.params_of(g, "%s__" % v)
+        sc.set_params_flat(p)
+        c = sc.colors_at(xs.ravel(), ys.ravel(), w, h)
+        o = ob.OracleScene(3, g["origin"], g["axes"], flat=flat, params=p, clean_normals=True).colors_at(xs.ravel(), ys.ravel(), w, h)
+        d = np.abs(c - o).max(axis=1)
+        assert d.max() < TOL_ORACLE, (str(v), float(d.max()), int((d > TOL_ORACLE).sum()))
+        # and against the reference itself: equal except where its o_hit.normal aliasing bites (see DESIGN.md)
+        dr = np.abs(c.reshape(h, w, 3) - g["%s__colors" % v]).max(axis=2)
+        assert (dr > TOL_REF).sum() < 0.06 * dr.size, str(v)
+    img = render_host(sc, fmt_of(w, h, fx.RGB16))
+    ref = ob.OracleScene(3, g["origin"], g["axes"], flat=flat, params=p, clean_normals=True).render(w, h, fx.RGB16, threads=3)
+    assert np.abs(img.astype(int) - ref.astype(int)).max() <= 1
+
+
 def test_shadow_rays_are_counted():
     g = fx.load("feature3d")
     flat = fx.flat_of(g, opaque=True)
