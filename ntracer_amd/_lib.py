@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libntracer_hip.so")
+LIB_PATH = os.environ.get("NTRACER_HIP_LIB") or os.path.join(_HERE, "libntracer_hip.so")   # override: A/B builds
 
 NT_OK = 0
 NT_ABORTED = 1

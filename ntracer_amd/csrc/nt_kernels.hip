@@ -188,6 +188,10 @@ __device__ __forceinline__ void emit_pixel(const NtTarget &tg, const PixelRef &p
         return;
     }
     uint8_t *p = tg.dest + pr.offset;
+#ifdef NT_EXP_SKIP_PACK
+    *reinterpret_cast<uint32_t *>(p) = __float_as_uint(r + g + b);
+    return;
+#endif
     if (tg.pack_mode == NT_PACK_WORD32) {
         const uint32_t w = pack_word32(r, g, b, tg);
         if (tg.bpp == 4 && tg.aligned4) {
@@ -250,14 +254,17 @@ __device__ __forceinline__ void primary_dir(const NtTarget &tg, const float (&ri
 // box_scene::calculate_color + hypercube_intersects (tracer.hpp:101-152).
 //
 // The reference tries the entry face of every axis i in ascending order; face i is the hit when
-// dist_i = (s_i - o_i)/d_i > 0 and |o_j + d_j*dist_i| <= 1+FUZZ for all j != i.  The same predicate is
-// evaluated here, bit for bit, but in an order that lets whole waves skip work:
-//   1. a ray whose distance from the centre exceeds the cube's circumradius (with a 0.1 % margin, far
-//      above any rounding) cannot satisfy the predicate for any face -> waves of such rays skip all faces;
-//   2. the AND over j is order-independent, so each face is first checked against ONE wave-uniform axis K
-//      (the axis entered last by the wave's first candidate ray); faces that fail it for every lane --
-//      all but one or two in a coherent wave -- skip the remaining N-2 checks;
-//   3. faces no lane can enter (dist <= 0 for the whole wave) skip their division.
+// dist_i = (s_i - o_i)/d_i > 0 and |o_j + d_j*dist_i| <= 1+FUZZ for all j != i.  That predicate is evaluated
+// here bit for bit, but only for the faces that can satisfy it:
+//   1. a ray whose distance from the centre exceeds the cube's circumradius (0.1 % margin) satisfies it for
+//      no face: such waves skip everything;
+//   2. let K be the candidate face reached LAST (largest dist; found by cross-multiplication, no division).
+//      A candidate i reached earlier than K by more than a sliver is still outside slab K at t = dist_i:
+//      |o_K + d_K*dist_i| = 1 + |d_K|*(dist_K - dist_i) > 1 + FUZZ, so it fails the reference's own j = K check.
+//      With a = |s - o|, b = |d| (dist = a/b), "more than a sliver" is  a_i*b_K < b_i*(a_K - mu),
+//      mu = 1e-4*(1+|o_K|) -- ~100x the rounding error of the quantities compared and of the reference's
+//      check.  Only the remaining near-ties (normally just K) get the division and the N-1 checks, in
+//      ascending order, exactly as the reference computes them.
 template <int N>
 __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir)[N], float &r, float &g, float &b) {
     bool done = false;     // a face passed the slab test (hit, or dist >= cutoff)
@@ -267,57 +274,52 @@ __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir
 #pragma unroll
     for (int j = 1; j < N; ++j) { osq += o[j] * o[j]; od += o[j] * dir[j]; }
     const float rad2 = (float)N * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
+#ifdef NT_EXP_SKIP_SLABS
+    const bool maybe = false;
+#else
     const bool maybe = !((osq - od * od) > rad2);            // NaN -> maybe
+#endif
 
     if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
-        float dist[N];
-        bool cand[N];
-        float dmax = -1.0f;
-        int kmax = -1;
+        float num[N];
+        bool pre[N];
+        // candidates: dist > 0 needs a non-zero numerator with the sign of d_i; track the last-reached one
+        float aK = 0.0f, bK = 1.0f, oK = 0.0f;
+        bool any = false;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const float di = dir[i];
             const float s = di < 0.0f ? 1.0f : -1.0f;
-            const float num = s - o[i];
-            // dist > 0 needs a non-zero numerator with the sign of di
-            const bool pre = maybe && di != 0.0f && ((num > 0.0f && di > 0.0f) || (num < 0.0f && di < 0.0f));
-            dist[i] = 0.0f;
-            cand[i] = false;
-            if (__builtin_amdgcn_ballot_w64(pre) != 0ull) {
-                dist[i] = num / di;
-                cand[i] = pre && dist[i] > 0.0f;
-            }
-            if (cand[i] && dist[i] > dmax) { dmax = dist[i]; kmax = i; }
+            num[i] = s - o[i];
+            pre[i] = maybe && ((num[i] > 0.0f && di > 0.0f) || (num[i] < 0.0f && di < 0.0f));
+            const float a = fabsf(num[i]), bb = fabsf(di);
+            // a/bb > aK/bK  <=>  a*bK > aK*bb   (all positive)
+            if (pre[i] && (!any || a * bK > aK * bb)) { aK = a; bK = bb; oK = o[i]; any = true; }
         }
-        const unsigned long long has = __builtin_amdgcn_ballot_w64(kmax >= 0);
-        if (has != 0ull) {
-            const int K = __builtin_amdgcn_readlane(kmax, (int)__builtin_ctzll(has));
-            float dK = dir[0], oK = o[0];
+        const float mu = 1e-4f * (1.0f + fabsf(oK));
+        const float aKm = (aK - mu) * (1.0f - 1e-6f);
 #pragma unroll
-            for (int k = 1; k < N; ++k) if (K == k) { dK = dir[k]; oK = o[k]; }
+        for (int i = 0; i < N; ++i) {
+            // near-tie with the last-reached face (always true for that face itself); NaN-safe: !(x < y)
+            const bool tie = pre[i] && !done && !(fabsf(num[i]) * bK < fabsf(dir[i]) * aKm);
+            if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {
+                const float di = dir[i];
+                const float dist = num[i] / di;
+                bool ok = tie && dist > 0.0f;
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                bool ok = cand[i] && !done;
-                if (i != K) {
-                    const float p = dK * dist[i] + oK;
-                    ok = ok && !(fabsf(p) > (1.0f + NT_FUZZ));
-                }
-                if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
-#pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        if (j != i) {
-                            const float p = dir[j] * dist[i] + o[j];
-                            ok = ok && !(fabsf(p) > (1.0f + NT_FUZZ));
-                        }
+                for (int j = 0; j < N; ++j) {
+                    if (j != i) {
+                        const float p = dir[j] * dist + o[j];
+                        ok = ok && !(fabsf(p) > (1.0f + NT_FUZZ));
                     }
-                    if (ok) {
-                        done = true;
-                        // `if(dist >= cutoff) return 0` with cutoff = FLT_MAX (tracer.hpp:142): a miss
-                        if (dist[i] >= FLT_MAX) shade = -1.0f;
-                        else {
-                            const float sine = dir[i] * (dir[i] < 0.0f ? 1.0f : -1.0f);   // dot(dir, s*e_i)
-                            shade = sine <= 0.0f ? -sine : 0.0f;
-                        }
+                }
+                if (ok) {
+                    done = true;
+                    // `if(dist >= cutoff) return 0` with cutoff = FLT_MAX (tracer.hpp:142): a miss
+                    if (dist >= FLT_MAX) shade = -1.0f;
+                    else {
+                        const float sine = di * (di < 0.0f ? 1.0f : -1.0f);   // dot(dir, s*e_i)
+                        shade = sine <= 0.0f ? -sine : 0.0f;
                     }
                 }
             }
