@@ -185,6 +185,14 @@ def main():
     kernel_us = dev_ms * 1e3 / launches                       # average launch duration (HIP events)
     total_bytes = float(own_rows) * W * fmt.bytes_per_pixel * args.steps         # algorithmic: framebuffer write only
     achieved = total_bytes / (dev_ms * 1e-3) / 1e9
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (separate runs; cannot be sampled live)
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        if world == 1 and prof.get("frames_per_launch") == F:
+            traffic = prof["write_bytes_per_launch"] + prof["fetch_bytes_per_launch_corrected"]
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "metric": "Mrays/s (primary+shadow), 6-D hypercube @1920x1080",
         "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,7 +203,8 @@ def main():
                    "tiling": "32-row bands round-robin over ranks" if world > 1 else "single GPU",
                    "framebuffer": "resident in HBM (one buffer per frame)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": float(own_rows) * W * fmt.bytes_per_pixel * min(F, args.steps),
                      "kernel": "box_kernel<6>", "avg_launch_us": round(kernel_us, 2),
                      "algorithmic_bytes_per_ray": fmt.bytes_per_pixel,
                      "note": "BoxScene reads no scene memory: the only algorithmic HBM traffic is the packed framebuffer "

@@ -1979,7 +1979,7 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
     bool active = valid && dist0 >= 0.0f;
     float t_near = dist0, t_far = FLT_MAX;
     int dirty = 0;
-    float st_t[DEPTH], st_f[DEPTH];
+    float st_t[DEPTH];       // per level: this lane's split distance if it entered BOTH sides there, else NaN
     mbox_reset(w, lane);
 
     int node = sc.root;      // wave-uniform
@@ -2045,8 +2045,10 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
                 break;
             }
             // ---- branch: kd_node_intersection::operator() (tracer.hpp:1189-1240)
-            const int axis = nd.axis;                          // uniform -> M0-indexed register reads
-            const float oa = o[axis], inv = invd[axis];        // oa is the same in every lane (shared origin)
+            const int axis = nd.axis;                          // uniform: select chains, no indexed access
+            float oa = o[0], inv = invd[0];                    // oa is the same in every lane (shared origin)
+#pragma unroll
+            for (int k = 1; k < N; ++k) { oa = axis == k ? o[k] : oa; inv = axis == k ? invd[k] : inv; }
             const bool gt = __builtin_amdgcn_readfirstlane((int)(oa > nd.split)) != 0;
             const int n_near = gt ? nd.right : nd.left;
             const int n_far = gt ? nd.left : nd.right;
@@ -2083,7 +2085,6 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
                         ustack[sp * 4 + 2] = (int)(unsigned int)(m_far >> 32);
                     }
                     st_t[sp] = both ? t : __int_as_float(0x7fc00000);
-                    st_f[sp] = t_far;
                     ++sp;
                 }
                 if (both && near_lane) t_far = t;
@@ -2103,13 +2104,22 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
         const int far = __builtin_amdgcn_readfirstlane(ustack[sp * 4 + 0]);
         const unsigned long long m = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 4 + 2]) << 32) |
                                      (unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 4 + 1]);
-        const float et = st_t[sp], ef = st_f[sp];
+        const float et = st_t[sp];
         const bool near_hit = sp < dirty;
         if (dirty > sp) dirty = sp;
         bool join = ((m >> lane) & 1ull) != 0ull;
-        if (join && et == et) {                            // a `both` lane: (hit && o_hit.dist <= t) -> return
-            if (near_hit && hit.dist <= et) join = false;
-            else { t_near = et; t_far = ef; }
+        if (__builtin_amdgcn_ballot_w64(join && et == et) != 0ull) {
+            // t_far of the frame being resumed = the split of the innermost pending branch below that this lane
+            // entered on both sides (its near subtree is where we are); none: the root's t_far
+            float ef = FLT_MAX;
+            for (int k = 0; k < sp; ++k) {
+                const float v = st_t[k];
+                ef = v == v ? v : ef;
+            }
+            if (join && et == et) {                        // a `both` lane: (hit && o_hit.dist <= t) -> return
+                if (near_hit && hit.dist <= et) join = false;
+                else { t_near = et; t_far = ef; }
+            }
         }
         active = join;
         node = far;
@@ -2183,13 +2193,17 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
         pk.tiles_x = (tg.width + 7) / 8;
         const int tiles = pk.tiles_x * ((tg.row_count + 7) / 8);
         const dim3 pgrid((unsigned)tiles, (unsigned)li.nframes);
-        if (sc.stack_depth <= 16) {
-            const size_t plds = (size_t)64 * NT_MBOX * 4 + (size_t)16 * 16;
-            hipLaunchKernelGGL((composite_packet<N, 16>), pgrid, dim3(64), plds, s, sc, tg, pk);
-        } else {
-            const size_t plds = (size_t)64 * NT_MBOX * 4 + (size_t)32 * 16;
-            hipLaunchKernelGGL((composite_packet<N, 32>), pgrid, dim3(64), plds, s, sc, tg, pk);
-        }
+#define NT_PACKET_CASE(D)                                                                                   \
+    if (sc.stack_depth <= D) {                                                                              \
+        const size_t plds = (size_t)64 * NT_MBOX * 4 + (size_t)D * 16;                                      \
+        hipLaunchKernelGGL((composite_packet<N, D>), pgrid, dim3(64), plds, s, sc, tg, pk);                 \
+        return 0;                                                                                           \
+    }
+        NT_PACKET_CASE(12)
+        NT_PACKET_CASE(20)
+        NT_PACKET_CASE(28)
+        NT_PACKET_CASE(32)
+#undef NT_PACKET_CASE
         return 0;
     }
     if (!feat && !sc.stats && !tg.colors_out && li.persist_counter) {
