@@ -133,7 +133,7 @@ typedef struct {
     int32_t band_world;          /* 0 or 1 => whole image */
     int32_t band_rows;           /* 0 => NT_RENDER_CHUNK_SIZE */
     int32_t compact;             /* 1: dest holds only the owned rows, packed in band order */
-    int32_t strict_reference;    /* 1 (default when opts==NULL): reference traversal order and quirks */
+    int32_t strict_reference;    /* reserved, must be 0 or 1: the kernels always follow the reference's traversal order and quirks */
     int32_t collect_stats;       /* 1: count rays/nodes/tests with device atomics (slower) */
     int32_t reserved;
 } nt_render_opts;
