@@ -1991,12 +1991,23 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
             if (nd.axis < 0) {
                 // ---- leaf: kd_leaf<Store,true>::intersects (tracer.hpp:977-1086), batches only
                 bool improved = false;
+                // software pipeline over the leaf's items: the id of item i+1 is fetched with item i's plane
+                // records, and its mailbox lookup (LDS) is issued before item i's edge tests, so neither
+                // round trip sits on the critical path
+                int item = __builtin_amdgcn_readfirstlane(sc.items[nd.left]);
+                bool doit = false;
+                if (active) doit = !mbox_seen(w, lane, item);
                 for (int i = 0; i < nd.right; ++i) {
-                    const int item = __builtin_amdgcn_readfirstlane(sc.items[nd.left + i]);
-                    bool doit = false;
-                    if (active) doit = !mbox_seen(w, lane, item);
-                    if (__builtin_amdgcn_ballot_w64(doit) == 0ull) continue;
-                    const float *base = sc.batch_recs + (size_t)(item >> 2) * NT_DEV_BATCH * sc.rec_stride;
+                    const int cur = item;
+                    const bool cur_doit = doit;
+                    const bool more = i + 1 < nd.right;
+                    if (more) item = __builtin_amdgcn_readfirstlane(sc.items[nd.left + i + 1]);
+                    if (__builtin_amdgcn_ballot_w64(cur_doit) == 0ull) {
+                        doit = false;
+                        if (more && active) doit = !mbox_seen(w, lane, item);
+                        continue;
+                    }
+                    const float *base = sc.batch_recs + (size_t)(cur >> 2) * NT_DEV_BATCH * sc.rec_stride;
                     // stage 1 for the 4 simplices at once: only d, face_normal, p1 (9 + N-4.. floats) are fetched,
                     // so all plane tests share one scalar-memory round trip
                     float tl[NT_DEV_BATCH];
@@ -2013,13 +2024,15 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
                         tl[l] = -(no + rec[0]) / denom;
                         ok1[l] = denom != 0.0f && tl[l] >= 0.0f;
                     }
+                    doit = false;
+                    if (more && active) doit = !mbox_seen(w, lane, item);
                     float min_t = hit.dist;
                     int r = -1;
 #pragma unroll
                     for (int l = 0; l < NT_DEV_BATCH; ++l) {
                         // stage 2 only if some lane can still accept this simplex (same accept rule as below)
                         const float t = tl[l];
-                        if (__builtin_amdgcn_ballot_w64(doit && ok1[l] && t != 0.0f && t < min_t) == 0ull) continue;
+                        if (__builtin_amdgcn_ballot_w64(cur_doit && ok1[l] && t != 0.0f && t < min_t) == 0ull) continue;
                         const float *rec = base + (size_t)l * sc.rec_stride;
                         float pside[N];
 #pragma unroll
@@ -2038,7 +2051,7 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
                         ok = ok && tot <= (1.0f + NT_FUZZ);
                         if (ok && t != 0.0f && t < min_t) { min_t = t; r = l; }
                     }
-                    if (doit && r >= 0) { hit.dist = min_t; hit.item = item; hit.lane = r; improved = true; }
+                    if (cur_doit && r >= 0) { hit.dist = min_t; hit.item = cur; hit.lane = r; improved = true; }
                 }
                 if (improved) dirty = sp;
                 node = -1;

@@ -223,6 +223,26 @@ def test_cell120_full_size_properties_and_counters():
     assert per(st, "simplex_tests") >= 0.95 * per(oc, "simplex_tests")
 
 
+def test_three_composite_kernels_render_identical_frames(monkeypatch):
+    """Lean scenes can be rendered by the wave-uniform packet kernel (default), the persistent per-lane kernel
+    with ballot-driven ray refill, or the plain per-lane tile kernel.  All walk the reference tree in the
+    reference order, so their frames must be byte-identical (and equal the oracle's up to powf rounding)."""
+    g = fx.load("cell600_n4")
+    flat = fx.flat_of(g)
+    fmt = fmt_of(333, 217, fx.RGBF32)          # ragged size, float channels: colours compared bit for bit
+    frames = {}
+    for choice in ("0", "1", "2"):
+        monkeypatch.setenv("NTRACER_COMPOSITE_KERNEL", choice)
+        sc = tracern.CompositeScene.from_flat(4, flat)
+        sc._set_camera_arrays(g["origins"][77], g["axes"][77])
+        frames[choice] = render_host(sc, fmt)
+    assert np.array_equal(frames["0"], frames["1"])
+    assert np.array_equal(frames["0"], frames["2"])
+    ref = ob.OracleScene(4, g["origins"][77], g["axes"][77], flat=flat).render(333, 217, fx.RGBF32, threads=7)
+    got = frames["0"].view(">f4")
+    assert np.abs(got - ref.view(">f4")).max() < TOL_ORACLE
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
