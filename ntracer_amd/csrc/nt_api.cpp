@@ -342,7 +342,12 @@ void fill_composite(const nt_scene *s, const DeviceState *ds, NtCompositeDev &c,
 
 int check_renderable(const nt_scene *s) {
     if (s->composite) {
-        if (s->n > NT_MAX_FIXED_DIM) return fail(NT_E_UNSUPPORTED, "composite scenes are implemented for dimensions 3..%d (got %d)", NT_MAX_FIXED_DIM, s->n);
+        if (s->n > NT_MAX_FIXED_DIM) {
+            // run-time-n kernel: the feature set of the scripted configurations
+            const bool lights = !s->pl_color.empty() || !s->gl_color.empty();
+            if (s->n_solids || !s->all_opaque || s->any_reflective || lights)
+                return fail(NT_E_UNSUPPORTED, "composite scenes with more than %d dimensions support opaque, non-reflective simplices lit by the camera light only", NT_MAX_FIXED_DIM);
+        }
         if (!s->all_opaque && s->any_reflective && s->max_reflect_depth > 5)
             return fail(NT_E_UNSUPPORTED, "max_reflect_depth > 5 is not supported for scenes with transparent materials");
         if (s->nodes.size() >= (1u << 24)) return fail(NT_E_UNSUPPORTED, "k-d trees with 2^24 or more nodes are not supported");

@@ -1654,6 +1654,241 @@ __global__ __launch_bounds__(256) void composite_kernel_t(NtCameraFixed cam, NtC
     }
 }
 
+// --------------------------------------------------------------------------------------
+// CompositeScene, run-time n (9..64): the var_geometry.hpp path.  Per-lane kernel; the ray's n-vectors
+// (origin, direction, 1/direction, scratch) live in LDS as [k][lane], simplex records are read from global
+// memory component by component.  Feature set of the scripted configurations: batches and unbatched
+// triangles, opaque, camera light; anything else is refused by the host for n > 8.  Operation order is the
+// oracle's, so results are identical to the fixed-N kernels' where both exist.
+// --------------------------------------------------------------------------------------
+struct VarLds {
+    float2 *ray;     // [n][64] (origin, 1/direction)
+    float *dv;       // [n][64] direction
+    float *ps;       // [n][64] scratch: pside / camera rows
+    int *stack;      // [depth][64]
+    int *mbox;       // [NT_MBOX][64]
+};
+
+__device__ __forceinline__ size_t var_lds_bytes(int depth, int n) {
+    return (size_t)64 * ((size_t)n * 16 + (size_t)depth * 4 + (size_t)NT_MBOX * 4);
+}
+
+// triangle_batch::intersects lane / triangle::intersects with run-time n (tracer.hpp:411-440, 561-581)
+__device__ __forceinline__ float simplex_var(const float *__restrict__ rec, int n, const VarLds &L, int lane, bool scalar_form, float cutoff) {
+    float denom = 0.0f, no = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        const float fn = rec[1 + k];
+        const float pd = fn * L.dv[k * 64 + lane];
+        const float po = fn * L.ray[k * 64 + lane].x;
+        denom = k == 0 ? pd : denom + pd;
+        no = k == 0 ? po : no + po;
+    }
+    if (scalar_form && denom == 0.0f) return 0.0f;
+    const float t = -(no + rec[0]) / denom;
+    if (scalar_form && (t <= 0.0f || t >= cutoff)) return 0.0f;
+    bool ok = scalar_form ? true : (denom != 0.0f && t >= 0.0f);
+    for (int k = 0; k < n; ++k) L.ps[k * 64 + lane] = rec[1 + n + k] - (L.ray[k * 64 + lane].x + t * L.dv[k * 64 + lane]);
+    float tot = 0.0f;
+    for (int e = 0; e < n - 1; ++e) {
+        const float *en = rec + 1 + 2 * n + (size_t)e * n;
+        float area = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float p = en[k] * L.ps[k * 64 + lane];
+            area = k == 0 ? p : area + p;
+        }
+        if (scalar_form) ok = ok && !(area < -NT_FUZZ || area > (1.0f + NT_FUZZ));
+        else ok = ok && area >= -NT_FUZZ;
+        tot += area;
+    }
+    ok = ok && tot <= (1.0f + NT_FUZZ);
+    return ok ? t : 0.0f;
+}
+
+__global__ __launch_bounds__(64) void composite_kernel_var(NtCamera cam, NtCompositeDev sc, NtTarget tg, int n) {
+    extern __shared__ float2 lds_raw[];
+    const int lane = (int)threadIdx.x;
+    const int depth = sc.stack_depth;
+    VarLds L;
+    {
+        char *p = reinterpret_cast<char *>(lds_raw);
+        L.ray = reinterpret_cast<float2 *>(p);
+        L.dv = reinterpret_cast<float *>(p + (size_t)64 * n * 8);
+        L.ps = L.dv + (size_t)64 * n;
+        L.stack = reinterpret_cast<int *>(L.ps + (size_t)64 * n);
+        L.mbox = L.stack + (size_t)64 * depth;
+    }
+    WaveLds w;
+    w.ray = L.ray;
+    w.stack = L.stack;
+    w.mbox = L.mbox;
+    const PixelRef pr = tg.colors_out ? locate_pixel<8, 8>(tg, 0, 0, lane) : locate_pixel<8, 8>(tg, lane & 7, lane >> 3, lane);
+    if (!pr.valid) return;
+    const float *c = cam.buf ? cam.buf + (size_t)blockIdx.z * 4 * n : nullptr;
+
+    // ---- primary ray (tracer.hpp:60-76), direction into LDS
+    const float sx = tg.fovI * ((float)pr.x - tg.half_w);
+    const float sy = tg.fovI * ((float)pr.y - tg.half_h);
+    float sq = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        const float rk = c ? c[n + k] : cam.inl[n + k];
+        const float uk = c ? c[2 * n + k] : cam.inl[2 * n + k];
+        const float fk = c ? c[3 * n + k] : cam.inl[3 * n + k];
+        const float v = (fk + rk * sx) - uk * sy;
+        L.dv[k * 64 + lane] = v;
+        sq = k == 0 ? v * v : sq + v * v;
+    }
+    const float len = sqrtf(sq);
+    for (int k = 0; k < n; ++k) {
+        const float dk = L.dv[k * 64 + lane] / len;
+        L.dv[k * 64 + lane] = dk;
+        const float ok_ = c ? c[k] : cam.inl[k];
+        L.ray[k * 64 + lane] = make_float2(ok_, dk != 0.0f ? 1.0f / dk : __int_as_float(0x7fc00000));
+    }
+
+    // ---- aabb_distance (tracer.hpp:1892-1918)
+    float dist0 = -1.0f;
+    for (int i = 0; i < n && dist0 < 0.0f; ++i) {
+        const float di = L.dv[i * 64 + lane];
+        if (di == 0.0f) continue;
+        const float oi = L.ray[i * 64 + lane].x;
+        const float face = di > 0.0f ? sc.aabb[i] : sc.aabb[n + i];
+        float dist = (face - oi) / di;
+        int skip = i;
+        if (dist < 0.0f) { dist = 0.0f; skip = -1; }
+        bool ok = true;
+        for (int j = 0; j < n; ++j) {
+            if (j != skip) {
+                const float p = L.dv[j * 64 + lane] * dist + L.ray[j * 64 + lane].x;
+                if (p >= sc.aabb[n + j] || p <= sc.aabb[j]) { ok = false; break; }
+            }
+        }
+        if (ok) dist0 = dist;
+    }
+
+    Hit hit;
+    hit.dist = FLT_MAX; hit.item = -1; hit.lane = -1;
+    if (dist0 >= 0.0f) {
+        // ---- kd_node_intersection (same continuation stack as trace_closest)
+        mbox_reset(w, lane);
+        int node = sc.root, sp = 0, dirty = 0;
+        float t_near = dist0, t_far = FLT_MAX;
+        for (;;) {
+            while (node >= 0) {
+                const NtNode nd = sc.nodes[node];
+                if (nd.axis < 0) {
+                    bool improved = false;
+                    for (int i = 0; i < nd.right; ++i) {
+                        const int item = sc.items[nd.left + i];
+                        if (mbox_seen(w, lane, item)) continue;
+                        const int kind = item & 3, idx = item >> 2;
+                        if (kind == 0) {
+                            float min_t = hit.dist;
+                            int r = -1;
+                            for (int l = 0; l < NT_DEV_BATCH; ++l) {
+                                const float t = simplex_var(sc.batch_recs + ((size_t)idx * NT_DEV_BATCH + l) * sc.rec_stride, n, L, lane, false, 0.0f);
+                                if (t != 0.0f && t < min_t) { min_t = t; r = l; }
+                            }
+                            if (r >= 0) { hit.dist = min_t; hit.item = item; hit.lane = r; improved = true; }
+                        } else {
+                            const float t = simplex_var(sc.tri_recs + (size_t)idx * sc.rec_stride, n, L, lane, true, hit.dist);
+                            if (t != 0.0f) { hit.dist = t; hit.item = item; hit.lane = -1; improved = true; }
+                        }
+                    }
+                    if (improved) dirty = sp;
+                    node = -1;
+                    break;
+                }
+                const float2 oi = L.ray[nd.axis * 64 + lane];
+                const float oa = oi.x, inv = oi.y;
+                if (inv == inv) {
+                    if (oa == nd.split) { node = inv > 0.0f ? nd.right : nd.left; continue; }
+                    const float t = (nd.split - oa) * inv;
+                    const bool gt = oa > nd.split;
+                    const int n_near = gt ? nd.right : nd.left;
+                    const int n_far = gt ? nd.left : nd.right;
+                    if (t < 0.0f || t > t_far) { node = n_near; continue; }
+                    if (t < t_near) { node = n_far; continue; }
+                    if (n_near >= 0) {
+                        if (sp < depth) { L.stack[sp * 64 + lane] = node; ++sp; }
+                        t_far = t;
+                        node = n_near;
+                        continue;
+                    }
+                    node = n_far;
+                    t_near = t;
+                    continue;
+                }
+                node = oa >= nd.split ? nd.right : nd.left;
+            }
+            bool resumed = false;
+            while (sp > 0) {
+                --sp;
+                const NtNode nd = sc.nodes[L.stack[sp * 64 + lane]];
+                bool gt;
+                const float t = branch_t(w, lane, nd, gt);
+                const int far = gt ? nd.left : nd.right;
+                const bool near_hit = sp < dirty;
+                if (dirty > sp) dirty = sp;
+                if ((near_hit && hit.dist <= t) || far < 0) continue;
+                node = far;
+                t_near = t;
+                t_far = FLT_MAX;
+                if (sp > 0) {
+                    const NtNode up = sc.nodes[L.stack[(sp - 1) * 64 + lane]];
+                    bool g2;
+                    t_far = branch_t(w, lane, up, g2);
+                }
+                resumed = true;
+                break;
+            }
+            if (!resumed) break;
+        }
+    }
+
+    // ---- shading: ray_color's miss branch / base_color with the camera light (tracer.hpp:1829-1853, 1866)
+    Color3 col;
+    if (hit.item < 0) {
+        const float iv = L.dv[sc.bg_axis * 64 + lane];
+        col = iv >= 0.0f ? cadd(cscale(c3p(sc.bg1), iv), cscale(c3p(sc.bg2), 1.0f - iv))
+                         : cadd(cscale(c3p(sc.bg3), -iv), cscale(c3p(sc.bg2), 1.0f + iv));
+    } else {
+        const int kind = hit.item & 3, idx = hit.item >> 2;
+        const float *rec = kind == 0 ? sc.batch_recs + ((size_t)idx * NT_DEV_BATCH + hit.lane) * sc.rec_stride
+                                     : sc.tri_recs + (size_t)idx * sc.rec_stride;
+        float denom = 0.0f, fsq = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float fn = rec[1 + k];
+            const float pd = fn * L.dv[k * 64 + lane];
+            denom = k == 0 ? pd : denom + pd;
+            fsq = k == 0 ? fn * fn : fsq + fn * fn;
+        }
+        const float flen = sqrtf(fsq);
+        float dn = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float u = rec[1 + k] / flen;
+            const float ndk = denom > 0.0f ? -u : u;
+            const float p = L.dv[k * 64 + lane] * ndk;
+            dn = k == 0 ? p : dn + p;
+        }
+        const float sine = -dn;
+        const float *m = material_of(sc, hit.item, hit.lane);
+        Color3 light = c3(0.0f, 0.0f, 0.0f), specular = c3(0.0f, 0.0f, 0.0f);
+        float spec_a = 0.0f;
+        if (sc.camera_light && sine > 0.0f) {
+            light = cadd(light, c3(sine, sine, sine));
+            if (m[8] != 0.0f) {
+                const float base = powf(sine, m[9]) * m[8];
+                specular = cadd(specular, cscale(cscale(c3p(m + 3), base), (1.0f - spec_a)));
+                spec_a += base * (1.0f - spec_a);
+                specular = cscale(specular, spec_a);
+            }
+        }
+        const Color3 r0 = cadd(c3p(sc.ambient), cmul(c3p(m), light));
+        col = cadd(specular, cscale(r0, 1.0f - spec_a));
+    }
+    emit_pixel(tg, pr, col.r, col.g, col.b);
+}
+
 __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -2284,9 +2519,22 @@ int nt_launch_composite(const NtLaunchInfo &li, const NtCamera &cam, const NtCom
         case 6: r = launch_composite_fixed<6>(li, cam, sc, tg); break;
         case 7: r = launch_composite_fixed<7>(li, cam, sc, tg); break;
         case 8: r = launch_composite_fixed<8>(li, cam, sc, tg); break;
-        default:
-            snprintf(g_launch_error, sizeof(g_launch_error), "composite scenes with dimension %d are not supported yet (3..8)", li.n);
-            return -2;
+        default: {
+            if (li.n < 3 || li.n > NT_DEV_MAX_DIM) {
+                snprintf(g_launch_error, sizeof(g_launch_error), "unsupported dimension %d", li.n);
+                return -2;
+            }
+            // run-time-n kernel: one wave per 8x8 tile (probe mode: 64 probes per block)
+            dim3 grid;
+            grid_for(tg, 8, 8, li.nframes, grid);
+            const size_t lds = (size_t)64 * ((size_t)li.n * 16 + (size_t)sc.stack_depth * 4 + (size_t)NT_MBOX * 4);
+            if (lds > 160 * 1024) {
+                snprintf(g_launch_error, sizeof(g_launch_error), "scene too deep for the LDS budget (n %d, depth %d)", li.n, sc.stack_depth);
+                return -1;
+            }
+            hipLaunchKernelGGL(composite_kernel_var, grid, dim3(64), lds, (hipStream_t)li.stream, cam, sc, tg, li.n);
+            r = 0;
+        }
     }
     if (r) return r;
     return finish_launch("composite kernel launch");

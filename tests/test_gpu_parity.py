@@ -145,7 +145,7 @@ def test_ragged_and_tiny_images():
 
 
 # ------------------------------------------------------------------ CompositeScene (config 4)
-@pytest.mark.parametrize("name", ["cell600_n4", "cell120_n4"])
+@pytest.mark.parametrize("name", ["cell600_n4", "cell120_n4", "orthoplex5_n5", "simplex10_n10"])
 def test_polytope_vs_oracle_and_reference(name):
     g = fx.load(name)
     n = int(g["dimension"])

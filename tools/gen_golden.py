@@ -473,6 +473,10 @@ if __name__ == "__main__":
         "cell600": lambda: gen_polytope("cell600_n4", ["3", "3", "5"], 640, 360, [0, 5, 33, 77, 121], (9, 7)),
         "cell120": lambda: gen_polytope("cell120_n4", ["5/2", "3", "3"], 1920, 1080, [0, 11, 52, 97, 140], (37, 29)),
         "feature": gen_feature_scene,
+        # a 10-D simplex {3,3,3,3,3,3,3,3,3}: composite scene through the generic (var_geometry) module
+        "simplex10": lambda: gen_polytope("simplex10_n10", ["3"] * 9, 320, 200, [0, 9, 47, 120], (5, 3)),
+        # a 5-D cross-polytope-like {3,3,3,4}: 32 facets, fixed<5> module
+        "orthoplex5": lambda: gen_polytope("orthoplex5_n5", ["3", "3", "3", "4"], 320, 200, [0, 9, 47, 120], (5, 3)),
     }
     for k, f in jobs.items():
         if a.only is None or k in a.only:
