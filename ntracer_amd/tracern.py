@@ -3,15 +3,15 @@
 and primitive value types and the lights.  Scenes own a handle of the HIP library; everything
 else is a light fp32 value type used to describe a scene.
 
-Not mirrored yet (SURVEY section 8f "next"): the k-d builder (build_kdtree /
-build_composite_scene), prototypes, Triangle.from_points, pickling.
+Scene construction (Triangle.from_points/to_points, prototypes, build_kdtree, build_composite_scene) lives in
+``builder.py``: SURVEY section 8f item 1.  Not mirrored: pickling, TriangleBatchPointData-style introspection.
 """
 import ctypes as C
 import math
 
 import numpy as np
 
-from . import _lib
+from . import _lib, builder
 from .render import Color, Material, Scene
 
 BATCH_SIZE = _lib.NT_BATCH_SIZE     # tracer.hpp:34-38 (SSE reference build)
@@ -340,6 +340,17 @@ class Triangle(Primitive):
         self.d = -dot(self.face_normal, self.p1)       # recalculate_d (tracer.hpp:472-474)
 
     dimension = property(lambda s: s.p1.dimension)
+
+    @staticmethod
+    def from_points(points, material):
+        """Triangle.from_points(points,material) -- tracer.hpp:442-462."""
+        p1, fn, edges = builder.from_points_record([list(p) for p in points])
+        return Triangle(p1, fn, edges, material)
+
+    def to_points(self):
+        """Triangle.to_points() -- tracer.hpp:490-506."""
+        pts = builder.to_points_array(self.p1._v, self.face_normal._v, [e._v for e in self.edge_normals])
+        return tuple(Vector._wrap(p) for p in pts)
 
     def _record(self):
         rec = [f32(self.d)] + list(self.face_normal._v) + list(self.p1._v)
@@ -772,9 +783,83 @@ def screen_coord_to_ray(cam, x, y, w, h, fov):
     return Vector._wrap(v).unit()
 
 
-def build_kdtree(*a, **k):
-    raise NotImplementedError("the k-d builder is not part of the MI355X ray-cast path yet (SURVEY section 8f, item 1)")
+def cross(vectors):
+    """tracern.cross(vectors) -- generalised cross product (geometry.hpp:884-892)."""
+    vs = list(vectors)
+    return Vector._wrap(builder.cross([v._v if isinstance(v, Vector) else list(v) for v in vs]).astype(f32))
 
 
-def build_composite_scene(*a, **k):
-    raise NotImplementedError("the k-d builder is not part of the MI355X ray-cast path yet (SURVEY section 8f, item 1)")
+class PrimitivePrototype(object):
+    """Base of the objects build_kdtree consumes: a primitive plus its bounding box (tracer.hpp:1363-1373)."""
+    boundary = None
+    primitive = None
+
+    @property
+    def dimension(self):
+        return self.boundary.dimension
+
+    @property
+    def material(self):
+        return self.primitive.material
+
+
+class TrianglePrototype(PrimitivePrototype):
+    """tracern.TrianglePrototype(points[,material]) -- tracer.hpp:1391-1405."""
+
+    def __init__(self, points, material=None):
+        pts = [list(p) for p in points]
+        if material is None:
+            # the reference also accepts (point, edge_normal) pairs from an existing prototype; not mirrored
+            raise TypeError("material is required")
+        self.primitive = Triangle.from_points(pts, material)
+        a = np.asarray(pts, f32)
+        n = a.shape[1]
+        self.boundary = AABB(n, a.min(axis=0), a.max(axis=0))
+        self.face_normal = self.primitive.face_normal
+        self.point_data = tuple(Vector._wrap(p) for p in a)
+
+
+class SolidPrototype(PrimitivePrototype):
+    """tracern.SolidPrototype(type,position,orientation,material) -- tracer.hpp:1375-1382."""
+
+    def __init__(self, type, position, orientation, material):
+        self.primitive = Solid(type, position, orientation, material)
+        lo, hi = builder.solid_bounds(type == CUBE, self.primitive.position._v, orientation._m)
+        self.boundary = AABB(orientation.dimension, lo, hi)
+        self.type = type
+        self.position = self.primitive.position
+        self.orientation = orientation
+        self.inv_orientation = self.primitive.inv_orientation
+
+
+def build_kdtree(primitives, extra_threads=-1, **kwds):
+    """tracern.build_kdtree(primitives[,extra_threads=-1,*,update_primitives=False]) -> (AABB, KDNode)
+    (ntracer_body.hpp:3250-3325, tracer.hpp:2431-2455).  ``extra_threads`` is accepted for compatibility."""
+    max_depth = int(kwds.pop("max_depth", builder.KD_DEFAULT_MAX_DEPTH))
+    split_threshold = int(kwds.pop("split_threshold", builder.KD_DEFAULT_SPLIT_THRESHOLD))
+    kwds.pop("update_primitives", None)
+    kwds.pop("traversal_cost", None)
+    kwds.pop("intersection_cost", None)
+    if kwds:
+        raise TypeError("unexpected keyword argument %r" % next(iter(kwds)))
+    protos = list(primitives)
+    if not protos:
+        raise ValueError("cannot build tree from empty sequence")
+    for p in protos:
+        if not isinstance(p, PrimitivePrototype):
+            raise TypeError("object is not an instance of PrimitivePrototype")
+    n = protos[0].dimension
+    if any(p.dimension != n for p in protos):
+        raise TypeError("the primitive prototypes must all have the same dimension")
+    tri = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v) for p in protos if isinstance(p, TrianglePrototype)]
+    other = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v) for p in protos if not isinstance(p, TrianglePrototype)]
+    batches, loose = builder.group_batches(tri, BATCH_SIZE, TriangleBatch)
+    lo, hi, root = builder.build_tree(batches + loose + other, KDLeaf, KDBranch, max_depth, split_threshold)
+    return AABB(n, lo, hi), root
+
+
+def build_composite_scene(primitives, extra_threads=-1, **kwds):
+    """tracern.build_composite_scene(primitives[,extra_threads=-1,*,update_primitives=False]) -> CompositeScene
+    (ntracer_body.hpp:3335-3357)."""
+    boundary, root = build_kdtree(primitives, extra_threads, **kwds)
+    return CompositeScene(boundary, root)

@@ -74,7 +74,8 @@ class NTracer(object):
         obj.BoxScene = _bind_dimension(tracern.BoxScene, dimension)
         obj.AABB = _bind_dimension(tracern.AABB, dimension)
         for n in ("CompositeScene", "KDNode", "KDLeaf", "KDBranch", "Primitive", "PrimitiveBatch", "Solid", "Triangle",
-                  "TriangleBatch", "PointLight", "GlobalLight", "dot", "build_kdtree", "build_composite_scene",
+                  "TriangleBatch", "TrianglePrototype", "SolidPrototype", "PrimitivePrototype", "PointLight", "GlobalLight",
+                  "dot", "cross", "build_kdtree", "build_composite_scene",
                   "screen_coord_to_ray", "BATCH_SIZE"):
             setattr(obj, n, getattr(tracern, n))
         if not force_generic:

@@ -1,0 +1,144 @@
+"""Scene construction on our side: Triangle.from_points / to_points against the reference's
+outputs, and build_kdtree / build_composite_scene against the tree-independence of the nearest hit."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+import ntracer_amd
+import oracle_binding as ob
+from ntracer_amd import builder, tracern
+from ntracer_amd.wrapper import NTracer
+
+MAT = ntracer_amd.Material((1, .5, .5))
+
+
+def test_from_points_and_to_points_match_reference():
+    g = fx.load("from_points")
+    for n in g["dims"]:
+        n = int(n)
+        for pts, rec, back in zip(g["points_n%d" % n], g["records_n%d" % n], g["to_points_n%d" % n]):
+            t = tracern.Triangle.from_points(pts, MAT)
+            mine = t._record()
+            scale = np.abs(rec).max()
+            assert np.abs(mine - rec).max() < 2e-5 * scale, n          # reference: fp32 LU, here: f64 determinants
+            # to_points mirrors the reference exactly, including its sign behaviour in even dimensions
+            tp = np.array([list(p) for p in t.to_points()], np.float32)
+            assert np.abs(tp - back).max() < 5e-5 * max(1.0, np.abs(back).max()), n
+            # ... and vertices_of() recovers the real vertices in every dimension
+            assert np.abs(builder.vertices_of(t.p1._v, t.face_normal._v, [e._v for e in t.edge_normals]) - pts).max() < 1e-4
+
+
+def test_cross_product_conventions():
+    nt = NTracer(3)
+    assert list(nt.cross([nt.Vector(1, 0, 0), nt.Vector(0, 1, 0)])) == [0, 0, 1]
+    v = tracern.cross([tracern.Vector(4, (1, 0, 0, 0)), tracern.Vector(4, (0, 1, 0, 0)), tracern.Vector(4, (0, 0, 1, 0))])
+    assert abs(abs(v[3]) - 1) < 1e-6 and v[0] == v[1] == v[2] == 0
+    with pytest.raises(ValueError):
+        tracern.cross([tracern.Vector(4, (1, 0, 0, 0))])
+
+
+def _flat_of_scene(boundary, root):
+    flat = tracern.CompositeScene._flatten(boundary, root)
+    flat["batch_size"] = 4
+    return flat
+
+
+def test_built_tree_renders_like_the_reference_tree():
+    """Rebuild the 600-cell from its vertices with OUR builder: the oracle on our tree must reproduce the
+    reference's pixels (captured on the reference's own tree) -- nearest hits are tree-independent."""
+    g = fx.load("cell600_n4")
+    recs = g["batch_recs"].reshape(-1, 21)
+    nt = NTracer(4)
+    protos = [nt.TrianglePrototype(builder.vertices_of(r[5:9], r[1:5], r[9:].reshape(3, 4)), MAT) for r in recs]
+    boundary, root = tracern.build_kdtree(protos)
+    assert np.allclose(list(boundary.start), g["aabb_start"], atol=1e-4) and np.allclose(list(boundary.end), g["aabb_end"], atol=1e-4)
+    flat = _flat_of_scene(boundary, root)
+    assert len(flat["batch_recs"]) == 150 and len(flat["tri_recs"]) == 0
+    for k in (0, 2):
+        f = g["frames"][k]
+        c, cnt = ob.OracleScene(4, g["origins"][f], g["axes"][f], flat=flat).colors_at(g["xs"], g["ys"], 640, 360, counters=True)
+        assert np.abs(c - g["colors"][k]).max() < 1e-4
+        assert cnt["batch_tests"] / cnt["rays"] < 40          # the tree actually prunes (150 batches in the scene)
+
+
+def test_tree_independence_with_solids_and_loose_triangles():
+    """A mixed 3-D scene (solids, 6 loose triangles + batches): the built tree must give the same colours as a
+    single leaf holding everything (brute force)."""
+    rnd = np.random.RandomState(5)
+    nt = NTracer(3)
+    mats = [ntracer_amd.Material((1, .5, .5)), ntracer_amd.Material((.2, .9, .3), 1, 0, .8, 12)]
+    protos = []
+    for i in range(22):
+        c = rnd.uniform(-3, 3, 3)
+        protos.append(nt.TrianglePrototype([c + rnd.uniform(-.9, .9, 3) for _ in range(3)], mats[i % 2]))
+    rot = nt.Matrix.rotation(nt.Vector(1, 0, 0), nt.Vector(0, 1, 0), .4) * nt.Matrix.scale(.7)
+    protos.append(nt.SolidPrototype(ntracer_amd.CUBE, nt.Vector(1, .3, -.5), rot, mats[0]))
+    protos.append(nt.SolidPrototype(ntracer_amd.SPHERE, nt.Vector(-1.2, .2, .6), nt.Matrix.scale(.8), mats[1]))
+    boundary, root = tracern.build_kdtree(protos)
+    flat = _flat_of_scene(boundary, root)
+    assert len(flat["batch_recs"]) == 5 and len(flat["tri_recs"]) == 2 and len(flat["solid_recs"]) == 2
+    # brute force: one leaf with every primitive
+    every = []
+
+    def collect(node):
+        if node is None:
+            return
+        if isinstance(node, tracern.KDLeaf):
+            for p in node:
+                if not any(p is q for q in every):
+                    every.append(p)
+        else:
+            collect(node.left)
+            collect(node.right)
+
+    collect(root)
+    brute = _flat_of_scene(boundary, tracern.KDLeaf(every))
+    cam_o = np.array([.3, .5, -8], np.float32)
+    ys, xs = np.mgrid[0:60, 0:80]
+    a = ob.OracleScene(3, cam_o, np.eye(3), flat=flat, clean_normals=True).colors_at(xs.ravel(), ys.ravel(), 80, 60)
+    b = ob.OracleScene(3, cam_o, np.eye(3), flat=brute, clean_normals=True).colors_at(xs.ravel(), ys.ravel(), 80, 60)
+    assert np.abs(a - b).max() < 1e-6
+    assert (a.max(axis=1) > 0).any()
+    # solids' bounding boxes contain the solids
+    sp = protos[-2]
+    u = rnd.uniform(-1, 1, (200, 3))
+    world = (rot._m.astype(np.float64) @ (u + np.array(list(sp.position))).T).T
+    assert (world >= np.array(list(sp.boundary.start)) - 1e-5).all() and (world <= np.array(list(sp.boundary.end)) + 1e-5).all()
+
+
+def test_builder_argument_checks():
+    nt = NTracer(3)
+    with pytest.raises(ValueError):
+        tracern.build_kdtree([])
+    with pytest.raises(TypeError):
+        tracern.build_kdtree([object()])
+    with pytest.raises(ValueError):
+        nt.TrianglePrototype([(0, 0, 0), (1, 1, 1), (2, 2, 2)], MAT)       # collinear
+    p3 = nt.TrianglePrototype([(0, 0, 0), (1, 0, 0), (0, 1, 0)], MAT)
+    p4 = NTracer(4).TrianglePrototype(np.eye(4), MAT)
+    with pytest.raises(TypeError):
+        tracern.build_kdtree([p3, p4])
+    sc = tracern.build_composite_scene([p3])
+    assert isinstance(sc, tracern.CompositeScene) and sc.dimension == 3
+
+
+@pytest.mark.gpu
+def test_scene_from_our_builder_on_the_gpu():
+    g = fx.load("cell600_n4")
+    recs = g["batch_recs"].reshape(-1, 21)
+    nt = NTracer(4)
+    protos = [nt.TrianglePrototype(builder.vertices_of(r[5:9], r[1:5], r[9:].reshape(3, 4)), MAT) for r in recs]
+    scene = nt.build_composite_scene(protos)
+    boundary, root = tracern.build_kdtree(protos)
+    flat = _flat_of_scene(boundary, root)
+    f = g["frames"][3]
+    scene._set_camera_arrays(g["origins"][f], g["axes"][f])
+    c = scene.colors_at(g["xs"], g["ys"], 640, 360)
+    o = ob.OracleScene(4, g["origins"][f], g["axes"][f], flat=flat).colors_at(g["xs"], g["ys"], 640, 360)
+    assert np.abs(c - o).max() < 1e-5
+    assert np.abs(c - g["colors"][3]).max() < 1e-4            # and the reference's pixels, from the reference's tree
+    fmt = ntracer_amd.ImageFormat(320, 180, [ntracer_amd.Channel(*ch) for ch in fx.RGBX8])
+    buf = bytearray(fmt.pitch * 180)
+    assert ntracer_amd.BlockingRenderer().render(buf, fmt, scene)             # packet kernel on our tree
+    ref = ob.OracleScene(4, g["origins"][f], g["axes"][f], flat=flat).render(320, 180, fx.RGBX8, threads=3)
+    assert np.abs(np.frombuffer(bytes(buf), np.uint8).reshape(180, fmt.pitch).astype(int) - ref.astype(int)).max() <= 1

@@ -455,6 +455,33 @@ def gen_feature_scene():
           "tris", len(d["tri_recs"]), "solids", len(d["solid_recs"]))
 
 
+def gen_from_points():
+    """Triangle.from_points / to_points of the reference on seeded random simplices (tracer.hpp:442-506)."""
+    import random
+    rnd = random.Random(99)
+    out = {}
+    dims = [3, 4, 5, 6, 8]
+    for n in dims:
+        nt = NTracer(n)
+        mat = Material((1, 1, 1))
+        pts = np.array([[[rnd.uniform(-3, 3) for _ in range(n)] for _ in range(n)] for _ in range(12)], np.float32)
+        recs = []
+        back = []
+        for P in pts:
+            t = nt.Triangle.from_points([nt.Vector(*[float(v) for v in p]) for p in P], mat)
+            rec = [t.d] + list(t.face_normal) + list(t.p1)
+            for e in t.edge_normals:
+                rec += list(e)
+            recs.append(rec)
+            back.append([list(q) for q in t.to_points()])
+        out["points_n%d" % n] = pts
+        out["records_n%d" % n] = np.array(recs, np.float32)
+        out["to_points_n%d" % n] = np.array(back, np.float32)
+    out["dims"] = np.array(dims, np.int32)
+    np.savez_compressed(os.path.join(OUT, "from_points.npz"), **out)
+    print("wrote from_points")
+
+
 def gen_kdtree_known_answer():
     """Per-stage capture on the 600-cell: nearest-hit records through
     KDNode.intersects for a fan of rays (advisory, cross-checked in tests
@@ -473,6 +500,7 @@ if __name__ == "__main__":
         "cell600": lambda: gen_polytope("cell600_n4", ["3", "3", "5"], 640, 360, [0, 5, 33, 77, 121], (9, 7)),
         "cell120": lambda: gen_polytope("cell120_n4", ["5/2", "3", "3"], 1920, 1080, [0, 11, 52, 97, 140], (37, 29)),
         "feature": gen_feature_scene,
+        "from_points": gen_from_points,
         # a 10-D simplex {3,3,3,3,3,3,3,3,3}: composite scene through the generic (var_geometry) module
         "simplex10": lambda: gen_polytope("simplex10_n10", ["3"] * 9, 320, 200, [0, 9, 47, 120], (5, 3)),
         # a 5-D cross-polytope-like {3,3,3,4}: 32 facets, fixed<5> module
