@@ -166,6 +166,18 @@ class Matrix(object):
                 m[row, col] = x
         return Matrix._wrap(m)
 
+    @staticmethod
+    def reflection(a):
+        """Matrix.reflection(a): I - 2 a a^T / |a|^2 (geometry.hpp:602-608), fp32."""
+        av = a._v if isinstance(a, Vector) else np.asarray(list(a), f32)
+        n = len(av)
+        square = f32(dot(Vector._wrap(av), Vector._wrap(av)))
+        m = np.zeros((n, n), f32)
+        for row in range(n):
+            for col in range(n):
+                m[row, col] = f32(f32(1 if row == col else 0) - f32(f32(f32(f32(2) * av[row]) * av[col]) / square))
+        return Matrix._wrap(m)
+
     def __getitem__(self, i):
         return Vector._wrap(self._m[i].copy())
 
@@ -602,7 +614,12 @@ class CompositeScene(_SceneBase):
                     materials=np.asarray(mats, f32).reshape(-1, 10),
                     aabb_start=boundary.start._v, aabb_end=boundary.end._v)
 
+    def _flat_description(self):
+        """The flat arrays this scene was created from (layout of nt_scene_desc / tests/golden/*.npz)."""
+        return {k: np.array(v) for k, v in self._flat.items()}
+
     def _create(self, d):
+        self._flat = {k: np.array(d[k]) for k in _FLAT_KEYS}
         n = int(d["dimension"])
         rl = n * n + n + 1
         keep = {}

@@ -54,6 +54,9 @@ class _MatrixFactory(object):
     def rotation(self, a, b, theta):
         return tracern.Matrix.rotation(a, b, theta)
 
+    def reflection(self, a):
+        return tracern.Matrix.reflection(a)
+
 
 class NTracer(object):
     """NTracer(dimension[,force_generic=False]): helper that creates objects of one dimension.
