@@ -8,9 +8,10 @@ Workload (configs[2]): BoxScene(6) -- the scene of the reference's scripts/hyper
 tests/golden/box_n6_1920x1080.npz).  As scripted there are no lights and no shadows, so every ray is a
 primary ray.
 
-A step = one frame = 1920*1080 rays.  K steps are issued as multi-frame launches
-(nt_render_frames_device: one camera per frame, one framebuffer per frame resident in HBM), timed
-between barrier + torch.cuda.synchronize() pairs with HIP events on the launch stream.
+A step = one pass over the benchmark's batch of synthetic input: the 160 cameras of the rotation, i.e. 160 frames
+= 331 776 000 primary rays, issued as ONE multi-frame launch (nt_render_frames_device: one camera and one
+framebuffer per frame, all 1.3 GB resident in HBM).  K steps are timed between barrier +
+torch.cuda.synchronize() pairs, with HIP events on the launch stream for the kernel time.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): every frame is tiled across the ranks in
 32-row bands (band b -> rank b % N).  Pixels are independent: no collective in the timed region; total
@@ -41,9 +42,9 @@ RGBX8 = [(8, 1, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0, 0, 0)]
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1600)
-    ap.add_argument("--warmup", type=int, default=320)
-    ap.add_argument("--frames-per-launch", type=int, default=160)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
     opts.strict_reference = 1
     own_rows = len(ntd.owned_rows(H, rank, world))
     frame_bytes = own_rows * fmt.pitch
-    F = max(1, min(args.frames_per_launch, nrot))
+    F = max(1, min(args.frames_per_step, nrot))
     fb = torch.empty((F, frame_bytes), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
     L = _lib.lib()
@@ -104,15 +105,10 @@ def main():
                                              o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst),
                                              C.byref(opts), C.c_void_p(stream.cuda_stream)))
 
-    def run(frames, first=0):
-        done = 0
-        launches = 0
-        while done < frames:
-            c = min(F, frames - done)
-            launch(first + done, c)
-            done += c
-            launches += 1
-        return launches
+    def run(steps):
+        for _ in range(steps):
+            launch(0, F)
+        return steps
 
     def barrier():
         if dist is not None:
@@ -138,7 +134,7 @@ def main():
     wall = float(el.item())
     dev_ms = float(dv.item())
 
-    rays = float(W) * H * args.steps
+    rays = float(W) * H * F * args.steps
     value = rays / wall / 1e6
 
     # ---- delivery step, outside `value`: gather to rank 0 (RCCL) / D2H at N = 1
@@ -158,7 +154,7 @@ def main():
         gather_ok = None
         if rank == 0:
             whole = torch.empty(H * fmt.pitch, dtype=torch.uint8, device="cuda")
-            fidx = ((args.steps - 1) // F) * F % nrot + (reps - 1) % F     # camera of the slot gathered last
+            fidx = (reps - 1) % F                                         # camera of the slot gathered last
             o1 = np.ascontiguousarray(origins[[fidx % nrot]])
             a1 = np.ascontiguousarray(axes[[fidx % nrot]])
             _lib.check(L.nt_render_frames_device(scene._handle, C.c_void_p(whole.data_ptr()), H * fmt.pitch, 1,
@@ -183,7 +179,7 @@ def main():
     # correctness guard inside the bench: the last rendered frame's checksum equals a fresh single render
     ms_per_step = wall * 1e3 / args.steps
     kernel_us = dev_ms * 1e3 / launches                       # average launch duration (HIP events)
-    total_bytes = float(own_rows) * W * fmt.bytes_per_pixel * args.steps         # algorithmic: framebuffer write only
+    total_bytes = float(own_rows) * W * fmt.bytes_per_pixel * F * args.steps     # algorithmic: framebuffer write only
     achieved = total_bytes / (dev_ms * 1e-3) / 1e9
     # HBM traffic per launch from the committed rocprofv3 PMC passes (separate runs; cannot be sampled live)
     traffic = None
@@ -199,12 +195,12 @@ def main():
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BoxScene(6) 1920x1080 RGBX8, 160-frame RotatingCamera sequence (configs[2])",
-                   "rays_per_step": W * H, "shadow_rays": 0, "frames_per_launch": F, "launches": launches,
+                   "rays_per_step": W * H * F, "frames_per_step": F, "shadow_rays": 0, "launches": launches,
                    "tiling": "32-row bands round-robin over ranks" if world > 1 else "single GPU",
                    "framebuffer": "resident in HBM (one buffer per frame)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": float(own_rows) * W * fmt.bytes_per_pixel * min(F, args.steps),
+                     "algorithmic_bytes_per_launch": float(own_rows) * W * fmt.bytes_per_pixel * F,
                      "kernel": "box_kernel<6>", "avg_launch_us": round(kernel_us, 2),
                      "algorithmic_bytes_per_ray": fmt.bytes_per_pixel,
                      "note": "BoxScene reads no scene memory: the only algorithmic HBM traffic is the packed framebuffer "
@@ -212,7 +208,7 @@ def main():
                              "structurally small"},
         "delivery": {"what": "RCCL gather to rank 0" if world > 1 else "D2H copy to pinned host memory",
                      "ms_per_frame": round(gather_ms, 4), "verified_equal_to_single_gpu_frame": gather_ok,
-                     "value_incl_delivery": round(float(W) * H / ((ms_per_step + gather_ms) * 1e-3) / 1e6, 1)},
+                     "value_incl_delivery": round(float(W) * H * F / ((ms_per_step + gather_ms * F) * 1e-3) / 1e6, 1)},
     }
 
     if not args.no_cpu_baseline and world == 1:
