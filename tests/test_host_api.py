@@ -130,3 +130,30 @@ def test_wrapper_cache_and_scene_type_rules():
     assert tuple(c) == (1, 1, 2)
     d = tracern.screen_coord_to_ray(tracern.Camera(3), 10, 20, 640, 480, 0.8)
     assert abs(d.absolute() - 1) < 1e-6 and d[2] > 0.85
+
+
+def test_channels_from_surface_layouts():
+    from ntracer_amd.pygame_render import channels_from_surface
+
+    class Surf(object):
+        def __init__(self, nbytes, losses, shifts, masks):
+            self.n, self.l, self.s, self.m = nbytes, losses, shifts, masks
+        get_bytesize = lambda s: s.n
+        get_losses = lambda s: s.l
+        get_shifts = lambda s: s.s
+        get_masks = lambda s: s.m
+
+    # 32-bit XRGB (pygame's usual display format): pad8, R8, G8, B8
+    ch = channels_from_surface(Surf(4, (0, 0, 0, 8), (16, 8, 0, 0), (0xFF0000, 0xFF00, 0xFF, 0)))
+    assert [(c.bit_size, c.f_r, c.f_g, c.f_b) for c in ch] == [(8, 0, 0, 0), (8, 1, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1)]
+    # RGB565
+    ch = channels_from_surface(Surf(2, (3, 2, 3, 8), (11, 5, 0, 0), (0xF800, 0x07E0, 0x001F, 0)))
+    assert [(c.bit_size, c.f_r, c.f_g, c.f_b) for c in ch] == [(5, 1, 0, 0), (6, 0, 1, 0), (5, 0, 0, 1)]
+    # 24-bit BGR
+    ch = channels_from_surface(Surf(3, (0, 0, 0, 8), (0, 8, 16, 0), (0xFF, 0xFF00, 0xFF0000, 0)))
+    assert [(c.bit_size, c.f_r, c.f_b) for c in ch] == [(8, 0, 1), (8, 0, 0), (8, 1, 0)]
+    # RGBA8888 with alpha in the low byte
+    ch = channels_from_surface(Surf(4, (0, 0, 0, 0), (24, 16, 8, 0), (0xFF000000, 0xFF0000, 0xFF00, 0xFF)))
+    assert [(c.bit_size, c.f_c) for c in ch] == [(8, 0), (8, 0), (8, 0), (8, 1)]
+    with pytest.raises(TypeError):
+        channels_from_surface(Surf(1, (0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0)))
