@@ -354,21 +354,25 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
 // wave's accesses to component j hit 64 consecutive banks)
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg) {
-    extern __shared__ float lds_dir[];    // [n][256]
+    extern __shared__ float lds_dir[];    // [n][256] per-lane direction, then [4][n] camera rows (broadcast reads)
     const int tid = (int)threadIdx.x;
     const int n = cam.n;
+    float *camrow = lds_dir + (size_t)n * 256;
+    {
+        // stage the camera rows once per block: run-time-indexed kernel arguments would be one scalar load each
+        const float *src = cam.buf ? cam.buf + (size_t)blockIdx.z * 4 * n : nullptr;
+        for (int k = tid; k < 4 * n; k += 256) camrow[k] = src ? src[k] : cam.inl[k];
+    }
+    __syncthreads();
     const PixelRef pr = locate_pixel<64, 4>(tg, tid & 63, tid >> 6, tid);
     if (!pr.valid) return;
-    const float *c = cam.buf ? cam.buf + (size_t)blockIdx.z * 4 * n : nullptr;
+    const float *c = camrow;              // origin, right, up, forward
     float *dir = lds_dir + tid;           // dir[j] at dir[j*256]
     const float sx = tg.fovI * ((float)pr.x - tg.half_w);
     const float sy = tg.fovI * ((float)pr.y - tg.half_h);
     float sq = 0.0f;
     for (int j = 0; j < n; ++j) {
-        const float rj = c ? c[n + j] : cam.inl[n + j];
-        const float uj = c ? c[2 * n + j] : cam.inl[2 * n + j];
-        const float fj = c ? c[3 * n + j] : cam.inl[3 * n + j];
-        const float v = (fj + rj * sx) - uj * sy;
+        const float v = (c[3 * n + j] + c[n + j] * sx) - c[2 * n + j] * sy;
         dir[j * 256] = v;
         sq = j == 0 ? v * v : sq + v * v;
     }
@@ -377,27 +381,53 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
 
     bool done = false;
     float shade = 0.0f;
-    for (int i = 0; i < n && !done; ++i) {
-        const float di = dir[i * 256];
-        if (di == 0.0f) continue;
-        const float oi = c ? c[i] : cam.inl[i];
-        const float s = di < 0.0f ? 1.0f : -1.0f;
-        const float dist = (s - oi) / di;
-        if (!(dist > 0.0f)) continue;
-        bool ok = true;
-        for (int j = 0; j < n; ++j) {
-            if (j != i) {
-                const float oj = c ? c[j] : cam.inl[j];
-                const float p = dir[j * 256] * dist + oj;
-                if (fabsf(p) > (1.0f + NT_FUZZ)) { ok = false; break; }
-            }
+    // Same exact pruning as box_color<N> (see there): circumsphere rejection per wave, then only the faces in
+    // a near-tie with the last-reached candidate K get the division and the n-1 checks.
+    float osq = 0.0f, od = 0.0f;
+    for (int j = 0; j < n; ++j) {
+        const float oj = c[j];
+        osq = fmaf(oj, oj, osq);
+        od = fmaf(oj, dir[j * 256], od);
+    }
+    const float rad2 = (float)n * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
+    const bool maybe = !((osq - od * od) > rad2 * 1.0001f + 1e-5f * osq);       // FMA rounding covered by the margin
+    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+        float aK = 0.0f, bK = 1.0f, oK = 0.0f;
+        bool any = false;
+        for (int i = 0; i < n; ++i) {
+            const float di = dir[i * 256];
+            const float oi = c[i];
+            const float num = (di < 0.0f ? 1.0f : -1.0f) - oi;
+            const bool pre = maybe && ((num > 0.0f && di > 0.0f) || (num < 0.0f && di < 0.0f));
+            const float a = fabsf(num), bb = fabsf(di);
+            if (pre && (!any || a * bK > aK * bb)) { aK = a; bK = bb; oK = oi; any = true; }
         }
-        if (ok) {
-            done = true;
-            if (dist >= FLT_MAX) shade = -1.0f;
-            else {
-                const float sine = di * s;
-                shade = sine <= 0.0f ? -sine : 0.0f;
+        const float mu = 1e-4f * (1.0f + fabsf(oK));
+        const float aKm = (aK - mu) * (1.0f - 1e-6f);
+        for (int i = 0; i < n; ++i) {
+            const float di = dir[i * 256];
+            const float oi = c[i];
+            const float s = di < 0.0f ? 1.0f : -1.0f;
+            const float num = s - oi;
+            const bool pre = maybe && ((num > 0.0f && di > 0.0f) || (num < 0.0f && di < 0.0f));
+            const bool tie = pre && !done && !(fabsf(num) * bK < fabsf(di) * aKm);
+            if (__builtin_amdgcn_ballot_w64(tie) == 0ull) continue;
+            const float dist = num / di;
+            bool ok = tie && dist > 0.0f;
+            for (int j = 0; j < n; ++j) {
+                if (j != i) {
+                    const float oj = c[j];
+                    const float p = dir[j * 256] * dist + oj;
+                    ok = ok && !(fabsf(p) > (1.0f + NT_FUZZ));
+                }
+            }
+            if (ok) {
+                done = true;
+                if (dist >= FLT_MAX) shade = -1.0f;
+                else {
+                    const float sine = di * s;
+                    shade = sine <= 0.0f ? -sine : 0.0f;
+                }
             }
         }
     }
@@ -2503,7 +2533,7 @@ int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &t
         default: {
             dim3 grid;
             grid_for(tg, 64, 4, li.nframes, grid);
-            const size_t lds = (size_t)li.n * 256 * sizeof(float);
+            const size_t lds = ((size_t)li.n * 256 + (size_t)4 * li.n) * sizeof(float);
             hipLaunchKernelGGL(box_kernel_var, grid, dim3(256), lds, (hipStream_t)li.stream, cam, tg);
         }
     }
