@@ -290,6 +290,25 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
     ms = time_scene(sc, ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"][sel], g["axes"][sel], 8, 2)
     res["config4_cell120_1080p_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
     res["config4_ms_per_frame"] = round(ms, 3)
+    # SURVEY 8d byte model on the reference tree (oracle counters, frame 0: 32.1 branches, 4.68 leaves, 195 simplices)
+    bytes_per_ray = 16 * 32.1 + 8 * 4.68 + 195 * (4 + 4 * 21) + 4
+    res["config4_algorithmic_bytes_per_ray"] = round(bytes_per_ray)
+    res["config4_algorithmic_TB_s"] = round(bytes_per_ray * 1920 * 1080 / (ms * 1e-3) / 1e12, 2)
+    # the same scene with shadows on, one point light and one global light: primary + shadow rays
+    n = 4
+    sc.add_light(tracern.PointLight(tracern.Vector(n, (8.0, 9.0, -7.0, 3.0)), (60.0, 60.0, 60.0)))
+    sc.add_light(tracern.GlobalLight(tracern.Vector(n, (0.2, -1.0, 0.3, 0.1)).unit(), (0.5, 0.5, 0.5)))
+    sc.set_shadows(True)
+    w2, h2 = 960, 540
+    fmt2 = ntracer_amd.ImageFormat(w2, h2, chan)
+    sc._set_camera_arrays(g["origins"][0], g["axes"][0])
+    buf = bytearray(fmt2.pitch * h2)
+    ntracer_amd.BlockingRenderer().render(buf, fmt2, sc, collect_stats=True)
+    st = sc.last_stats()
+    ms2 = time_scene(sc, fmt2, g["origins"][sel], g["axes"][sel], 4, 2)
+    res["config4_shadows_960x540"] = {"primary_rays": st["rays"], "shadow_rays": st["shadow_rays"],
+                                      "Mrays_s_primary_plus_shadow": round((st["rays"] + st["shadow_rays"]) / ms2 / 1e3, 1),
+                                      "ms_per_frame": round(ms2, 3)}
     return res
 
 

@@ -447,8 +447,10 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         NtCompositeDev c;
         fill_composite(s, ds, c, job.stats);
         if (c.root < 0) c.root = -1;
-        const bool lean = !c.n_point_lights && !c.n_global_lights && !c.any_reflective && !c.has_scalar_prims;
-        if (lean && !job.stats && !job.colors_out && s->n <= NT_MAX_FIXED_DIM && li.kernel_choice != 2) {
+        // image renders of opaque scenes made of batches go through the packet kernel (primary rays share the
+        // camera origin): it needs the camera table in device memory (and, for the persistent variant, a counter)
+        const bool packetable = c.all_opaque && !c.has_scalar_prims;
+        if (packetable && !job.stats && !job.colors_out && s->n <= NT_MAX_FIXED_DIM && li.kernel_choice != 2) {
             // persistent kernel: a zeroed work counter and the camera table in device memory (stream ordered)
             if (int e = ds->counter.ensure(8)) return e;
             HIP_TRY(hipMemsetAsync(ds->counter.p, 0, 8, job.stream));

@@ -1073,8 +1073,11 @@ __device__ __forceinline__ Color3 surface_color_lean(const NtCompositeDev &sc, c
     return cadd(specular, cscale(r0, 1.0f - spec_a));
 }
 
+// `primary`: when not null, the closest hit of the depth-0 ray has already been found (by the packet walk) and
+// is taken from there instead of being traced here.
 template <int N, bool FEAT, bool STATS>
-__device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, const WaveLds &w, int lane, float (&o)[N], float (&d)[N], Stats &st) {
+__device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, const WaveLds &w, int lane, float (&o)[N], float (&d)[N], Stats &st,
+                                                  const Hit *primary = nullptr) {
     Level levels[FEAT ? NT_DEV_MAX_REFLECT : 1];
     int depth = 0;
     int skip_item = -1, skip_lane = -1;
@@ -1082,16 +1085,21 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
     for (;;) {
         // ---- ray_color (tracer.hpp:1856-1883) ----
         if (STATS) st.rays += 1;
-        const float dist = aabb_distance<N>(sc, o, d);
         Hit hit;
         hit.item = -1;
         hit.lane = -1;
         hit.dist = FLT_MAX;
         bool found = false;
-        if (dist >= 0.0f) {
-            if (STATS && depth == 0) st.aabb_enter += 1;
-            setup_ray_table<N>(w, lane, o, d);
-            found = trace_closest<N, FEAT, STATS>(sc, w, lane, o, d, dist, FLT_MAX, skip_item, skip_lane, hit, st);
+        if (primary && depth == 0) {
+            hit = *primary;
+            found = hit.item >= 0;
+        } else {
+            const float dist = aabb_distance<N>(sc, o, d);
+            if (dist >= 0.0f) {
+                if (STATS && depth == 0) st.aabb_enter += 1;
+                setup_ray_table<N>(w, lane, o, d);
+                found = trace_closest<N, FEAT, STATS>(sc, w, lane, o, d, dist, FLT_MAX, skip_item, skip_lane, hit, st);
+            }
         }
         if (!found) {
             result = background_color<N>(sc, d);
@@ -2202,14 +2210,17 @@ struct PacketArgs {
 // stack pointer is wave-uniform, so the arrays are indexed through M0 (s_set_gpr_idx), not spilled.  The ray's
 // origin / inverse direction are indexed the same way by the (uniform) split axis.  LDS only holds the
 // mailbox and the uniform (far node, lane mask) pairs, which keeps ~20 waves per CU resident.
-template <int N, int DEPTH>
+// FEAT = true: the packet walk finds the primary hits (batches only), then every lane shades its hit with the
+// general base_color -- lights, shadow rays (per-lane _occludes walks), reflections (per-lane closest-hit walks);
+// those secondary walks need the per-lane LDS stack + ray table, placed after the packet's own LDS.
+template <int N, int DEPTH, bool FEAT>
 __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarget tg, PacketArgs pa) {
     extern __shared__ float2 lds_raw[];
     const int lane = (int)threadIdx.x;
-    WaveLds w;              // view used by the shared helpers (mailbox only)
-    w.mbox = reinterpret_cast<int *>(lds_raw);
-    w.ray = nullptr;
-    w.stack = nullptr;
+    WaveLds w;              // view used by the shared helpers (mailbox; FEAT: also ray table and per-lane stack)
+    w.ray = lds_raw;                                                       // [N][64] float2 (FEAT only)
+    w.stack = reinterpret_cast<int *>(lds_raw + (FEAT ? 64 * N : 0));     // [stack_depth][64] (FEAT only)
+    w.mbox = w.stack + (FEAT ? 64 * sc.stack_depth : 0);
     int *ustack = w.mbox + 64 * NT_MBOX;          // [DEPTH][4]: far node, mask lo, mask hi, -
 
     // ---- this wave's tile
@@ -2404,7 +2415,13 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
     }
 
     if (valid) {
-        const Color3 c = hit.item >= 0 ? surface_color_lean<N>(sc, hit, o, d) : background_color<N>(sc, d);
+        Color3 c;
+        if (FEAT) {
+            Stats st = {0, 0, 0, 0, 0, 0, 0, 0};
+            c = composite_color<N, true, false>(sc, w, lane, o, d, st, &hit);
+        } else {
+            c = hit.item >= 0 ? surface_color_lean<N>(sc, hit, o, d) : background_color<N>(sc, d);
+        }
         uint8_t *p = tg.dest + out_off;
         if (tg.pack_mode == NT_PACK_WORD32) {
             const uint32_t wd = pack_word32(c.r, c.g, c.b, tg);
@@ -2464,8 +2481,8 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
         hipLaunchKernelGGL((composite_kernel_t<N>), grid, dim3(256), lds, s, cf, sc, tg);
         return 0;
     }
-    if (!feat && !sc.stats && !tg.colors_out && li.persist_cams && li.kernel_choice != 1 && sc.stack_depth <= 32) {
-        // packet kernel: one wave per 8x8 tile, wave-uniform tree walk
+    if (!sc.has_scalar_prims && !sc.stats && !tg.colors_out && li.persist_cams && li.kernel_choice == 0 && sc.stack_depth <= 32) {
+        // packet kernel: one wave per 8x8 tile, wave-uniform tree walk for the primary rays
         PacketArgs pk;
         pk.cams = li.persist_cams;
         pk.tiles_x = (tg.width + 7) / 8;
@@ -2473,8 +2490,13 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
         const dim3 pgrid((unsigned)tiles, (unsigned)li.nframes);
 #define NT_PACKET_CASE(D)                                                                                   \
     if (sc.stack_depth <= D) {                                                                              \
-        const size_t plds = (size_t)64 * NT_MBOX * 4 + (size_t)D * 16;                                      \
-        hipLaunchKernelGGL((composite_packet<N, D>), pgrid, dim3(64), plds, s, sc, tg, pk);                 \
+        if (feat) {                                                                                         \
+            const size_t plds = (size_t)64 * ((size_t)N * 8 + (size_t)sc.stack_depth * 4 + NT_MBOX * 4) + (size_t)D * 16; \
+            hipLaunchKernelGGL((composite_packet<N, D, true>), pgrid, dim3(64), plds, s, sc, tg, pk);       \
+        } else {                                                                                            \
+            const size_t plds = (size_t)64 * NT_MBOX * 4 + (size_t)D * 16;                                  \
+            hipLaunchKernelGGL((composite_packet<N, D, false>), pgrid, dim3(64), plds, s, sc, tg, pk);      \
+        }                                                                                                   \
         return 0;                                                                                           \
     }
         NT_PACKET_CASE(12)
@@ -2482,7 +2504,6 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
         NT_PACKET_CASE(28)
         NT_PACKET_CASE(32)
 #undef NT_PACKET_CASE
-        return 0;
     }
     if (!feat && !sc.stats && !tg.colors_out && li.persist_counter) {
         // persistent waves + ray refill

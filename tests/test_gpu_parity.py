@@ -243,6 +243,33 @@ def test_three_composite_kernels_render_identical_frames(monkeypatch):
     assert np.abs(got - ref.view(">f4")).max() < TOL_ORACLE
 
 
+def test_lit_reflective_polytope_packet_vs_tile_vs_oracle(monkeypatch):
+    """Lights, shadows and reflection on a batches-only scene: the packet kernel finds the primary hits and shades
+    per lane (shadow / reflection rays walk the tree per lane); the per-lane tile kernel does everything per lane.
+    Both must produce the same bytes, and the oracle's colours."""
+    g = fx.load("cell600_n4")
+    flat = fx.flat_of(g)
+    m = np.array(flat["materials"], np.float32).copy()
+    m[:, 7] = 0.3                                      # reflective
+    flat["materials"] = m
+    params = dict(fov=0.8, shadows=1, camera_light=1, max_reflect_depth=2, bg_gradient_axis=1,
+                  ambient=[.02, .02, .03], bg1=[1, 1, 1], bg2=[0, 0, 0], bg3=[0, 1, 1],
+                  point_light_pos=[[20.0, 15.0, -25.0, 5.0]], point_light_color=[[900.0, 800.0, 700.0]],
+                  global_light_dir=[[0.2, -0.9, 0.3, 0.1]], global_light_color=[[.4, .4, .5]])
+    fmt = fmt_of(240, 135, fx.RGBF32)
+    frames = {}
+    for choice in ("0", "2"):
+        monkeypatch.setenv("NTRACER_COMPOSITE_KERNEL", choice)
+        sc = tracern.CompositeScene.from_flat(4, flat)
+        sc.set_params_flat(params)
+        sc._set_camera_arrays(g["origins"][5], g["axes"][5])
+        frames[choice] = render_host(sc, fmt)
+    assert np.array_equal(frames["0"], frames["2"])
+    ref = ob.OracleScene(4, g["origins"][5], g["axes"][5], flat=flat, params=params).render(240, 135, fx.RGBF32, threads=7)
+    assert np.abs(frames["0"].view(">f4") - ref.view(">f4")).max() < TOL_ORACLE
+    assert frames["0"].view(">f4").max() > 0.5
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
