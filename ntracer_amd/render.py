@@ -359,7 +359,14 @@ class CallbackRenderer(object):
                 finally:
                     L.nt_scene_unlock(scene._handle)
                 if r == _lib.NT_OK:
-                    callback(self)
+                    try:
+                        callback(self)
+                    except Exception:                      # the reference prints and carries on (render.cpp:536-542)
+                        import traceback
+                        traceback.print_exc()
+                elif r < 0:
+                    import sys
+                    sys.stderr.write("error: %s\n" % _lib.last_error())
 
             self._worker = threading.Thread(target=work, daemon=True)
             self._worker.start()
