@@ -133,6 +133,45 @@ def test_pixel_packing_all_formats_bit_exact_vs_reference():
         assert (got[:, w * bpp:] == 0xAB).all(), "pitch padding must not be touched: %s" % name
 
 
+def test_random_channel_layouts_match_oracle_bytes():
+    """Seeded random formats: 1..9 channels, 1..31-bit integers and 32-bit floats, negative / > 1 weights, up to
+    128 bits, reversed or not, padded pitch -- through every packing path (32-bit, 64-bit, generic 128-bit)."""
+    rnd = np.random.RandomState(20260101)
+    g = fx.load("box_n5_320x200")
+    sc = tracern.BoxScene(5)
+    sc._set_camera_arrays(g["origins"][40], g["axes"][40])
+    osc = ob.OracleScene(5, g["origins"][40], g["axes"][40])
+    w, h = 53, 31
+    seen_modes = set()
+    for trial in range(48):
+        chans = []
+        bits = 0
+        for _ in range(rnd.randint(1, 10)):
+            if rnd.rand() < 0.2 and bits + 32 <= 128:
+                chans.append((32, float(rnd.uniform(-1, 2)), float(rnd.uniform(-1, 2)), float(rnd.uniform(-1, 2)), float(rnd.uniform(-.5, .5)), True))
+                bits += 32
+            else:
+                b = int(rnd.choice([1, 2, 5, 8, 10, 16, 24, 29, 30, 31]))
+                if bits + b > 128:
+                    break
+                if rnd.rand() < 0.25:
+                    chans.append((b, 0, 0, 0))                       # padding channel
+                else:
+                    chans.append((b, float(rnd.uniform(-1, 2)), float(rnd.uniform(-1, 2)), float(rnd.uniform(-1, 2)), float(rnd.uniform(-.5, .5))))
+                bits += b
+        if not chans:
+            continue
+        bpp = (bits + 7) // 8
+        pitch = w * bpp + int(rnd.choice([0, 0, 3, 8]))
+        rev = bool(rnd.rand() < 0.5)
+        live = sum(1 for c in chans if any(c[1:5]) or (len(c) > 5 and c[5]))
+        seen_modes.add("w32" if bits <= 32 and live <= 4 else "w64" if bits <= 64 and live <= 4 else "gen")
+        img = render_host(sc, fmt_of(w, h, chans, pitch, rev))
+        ref = osc.render(w, h, chans, pitch, rev)
+        assert np.array_equal(img[:, :w * bpp], ref[:, :w * bpp]), (trial, chans, rev)
+    assert seen_modes == {"w32", "w64", "gen"}
+
+
 def test_ragged_and_tiny_images():
     g = fx.load("box_n6_1920x1080")
     sc = tracern.BoxScene(6)
