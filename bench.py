@@ -89,7 +89,7 @@ def main():
     opts.band_rank = rank
     opts.band_world = world
     opts.compact = 1
-    opts.strict_reference = 1
+    opts.strict_reference = 0
     own_rows = len(ntd.owned_rows(H, rank, world))
     frame_bytes = own_rows * fmt.pitch
     F = max(1, min(args.frames_per_step, nrot))
@@ -255,8 +255,12 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
     res = {}
     G = os.path.join(ROOT, "tests", "golden")
 
-    def time_scene(scene, fmt, origins, axes, frames, reps):
+    def time_scene(scene, fmt, origins, axes, frames, reps, strict=False):
         fst = fmt._as_struct()
+        ropts = _lib.NtRenderOpts()
+        ropts.device = -1
+        ropts.band_world = 1
+        ropts.strict_reference = 1 if strict else 0
         fb = torch.empty((frames, fmt.pitch * fmt.height), dtype=torch.uint8, device="cuda")
         o = np.ascontiguousarray(origins[:frames], np.float32)
         a = np.ascontiguousarray(axes[:frames], np.float32)
@@ -264,7 +268,7 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
 
         def go():
             _lib.check(_lib.lib().nt_render_frames_device(scene._handle, C.c_void_p(fb.data_ptr()), fmt.pitch * fmt.height, frames,
-                                                          o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), None,
+                                                          o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(ropts),
                                                           C.c_void_p(st.cuda_stream)))
         go()
         torch.cuda.synchronize()
@@ -290,10 +294,17 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
     ms = time_scene(sc, ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"][sel], g["axes"][sel], 8, 2)
     res["config4_cell120_1080p_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
     res["config4_ms_per_frame"] = round(ms, 3)
-    # SURVEY 8d byte model on the reference tree (oracle counters, frame 0: 32.1 branches, 4.68 leaves, 195 simplices)
+    # the same frames walking exactly the cells the reference walks (nt_render_opts.strict_reference; same bytes)
+    ms_strict = time_scene(sc, ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"][sel], g["axes"][sel], 8, 2, strict=True)
+    res["config4_strict_reference_ms_per_frame"] = round(ms_strict, 3)
+    # SURVEY 8d byte model on the reference tree, oracle counters on frame 0: the reference's walk (32.1 branches,
+    # 4.68 leaves, 195 simplices per ray) and the default walk that drops cells beyond the hit (31.2 / 4.46 / 168)
     bytes_per_ray = 16 * 32.1 + 8 * 4.68 + 195 * (4 + 4 * 21) + 4
     res["config4_algorithmic_bytes_per_ray"] = round(bytes_per_ray)
-    res["config4_algorithmic_TB_s"] = round(bytes_per_ray * 1920 * 1080 / (ms * 1e-3) / 1e12, 2)
+    res["config4_algorithmic_TB_s"] = round(bytes_per_ray * 1920 * 1080 / (ms_strict * 1e-3) / 1e12, 2)
+    bytes_pruned = 16 * 31.2 + 8 * 4.46 + 168 * (4 + 4 * 21) + 4
+    res["config4_default_walk_bytes_per_ray"] = round(bytes_pruned)
+    res["config4_default_walk_TB_s"] = round(bytes_pruned * 1920 * 1080 / (ms * 1e-3) / 1e12, 2)
     # the same scene with shadows on, one point light and one global light: primary + shadow rays
     n = 4
     sc.add_light(tracern.PointLight(tracern.Vector(n, (8.0, 9.0, -7.0, 3.0)), (60.0, 60.0, 60.0)))

@@ -133,7 +133,10 @@ typedef struct {
     int32_t band_world;          /* 0 or 1 => whole image */
     int32_t band_rows;           /* 0 => NT_RENDER_CHUNK_SIZE */
     int32_t compact;             /* 1: dest holds only the owned rows, packed in band order */
-    int32_t strict_reference;    /* reserved, must be 0 or 1: the kernels always follow the reference's traversal order and quirks */
+    int32_t strict_reference;    /* 0: closest-hit walks skip k-d cells that start beyond the current hit (same pixels, far fewer
+                                    tests).  1: walk exactly the cells the reference walks
+                                    (src/tracer.hpp:1179-1243).  NTRACER_STRICT_REFERENCE=1 in the environment forces 1,
+                                    also for nt_colors_at / nt_calculate_color, which take no options. */
     int32_t collect_stats;       /* 1: count rays/nodes/tests with device atomics (slower) */
     int32_t reserved;
 } nt_render_opts;

@@ -78,6 +78,8 @@ struct DeviceState {
     DevBuf lights;                       // pl_pos | pl_color | gl_dir | gl_color
     unsigned long long lights_version = 0;
     DevBuf framebuffer, cams, probes, stats, counter;
+    struct TileOrder { int tx = 0, ty = 0; DevBuf buf; };
+    std::vector<std::unique_ptr<TileOrder>> tile_orders;   // packet kernel: tiles sorted centre-out, per tile grid
     int cu_count = 0;
     std::vector<std::unique_ptr<ChanTable>> chan_tables;
 };
@@ -388,6 +390,7 @@ struct FrameJob {
     const float *cam_buf;     // device [nframes][4][n] or nullptr
     hipStream_t stream;
     bool stats;
+    bool strict = false;      // nt_render_opts.strict_reference
     int row_begin, row_count; // owned-row slab
     // probe mode
     float *colors_out = nullptr;
@@ -441,11 +444,17 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     li.persist_cams = nullptr;
     li.cu_count = ds->cu_count;
     li.kernel_choice = 0;
+    li.tile_order = nullptr;
     if (const char *kc = getenv("NTRACER_COMPOSITE_KERNEL")) li.kernel_choice = atoi(kc);
     int r;
     if (s->composite) {
         NtCompositeDev c;
         fill_composite(s, ds, c, job.stats);
+        // closest-hit walks drop subtrees beyond the current hit unless the caller (or NTRACER_STRICT_REFERENCE=1)
+        // asks for the reference's exact walk; the pixels are the same (nt_beyond_hit in nt_kernels.hip)
+        const char *es = getenv("NTRACER_STRICT_REFERENCE");
+        const bool env_strict = es && atoi(es) != 0;
+        c.prune = (job.strict || env_strict) ? 0 : 1;
         if (c.root < 0) c.root = -1;
         // image renders of opaque scenes made of batches go through the packet kernel (primary rays share the
         // camera origin): it needs the camera table in device memory (and, for the persistent variant, a counter)
@@ -462,6 +471,39 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
                 HIP_TRY(hipMemcpyAsync(ds->cams.p, cam.inl, sizeof(float) * 4 * s->n, hipMemcpyHostToDevice, job.stream));
                 li.persist_cams = (const float *)ds->cams.p;
             }
+        }
+        const char *eto = getenv("NTRACER_TILE_ORDER");
+        if (li.persist_cams && !tg.colors_out && !(eto && atoi(eto) == 0)) {
+            // dispatch order of the packet kernel's quads (2x2 tiles of 8x8 pixels): the waves that walk the middle
+            // of the scene run longest, so the quad rows nearest the centre go first; row-major within a row keeps
+            // neighbouring blocks on neighbouring rays
+            const int tx = ((tg.width + 7) / 8 + 1) / 2, ty = ((tg.row_count + 7) / 8 + 1) / 2;
+            DeviceState::TileOrder *to = nullptr;
+            for (auto &e : ds->tile_orders)
+                if (e->tx == tx && e->ty == ty) to = e.get();
+            if (!to) {
+                std::vector<int> order((size_t)tx * ty);
+                for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+                auto key = [&](int t) {
+                    const long long dy = 2 * (t / tx) - (ty - 1);
+                    return dy < 0 ? -dy : dy;
+                };
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+                if (ds->tile_orders.size() >= 16) {
+                    // tables may still be read by launches queued on other streams
+                    HIP_TRY(hipDeviceSynchronize());
+                    for (auto &e : ds->tile_orders) e->buf.release();
+                    ds->tile_orders.clear();
+                }
+                std::unique_ptr<DeviceState::TileOrder> e(new DeviceState::TileOrder);
+                if (int err = e->buf.ensure(order.size() * sizeof(int))) return err;
+                HIP_TRY(hipMemcpy(e->buf.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+                e->tx = tx;
+                e->ty = ty;
+                to = e.get();
+                ds->tile_orders.push_back(std::move(e));
+            }
+            li.tile_order = (const int *)to->buf.p;
         }
         r = nt_launch_composite(li, cam, c, tg);
     } else {
@@ -642,6 +684,7 @@ void nt_scene_destroy(nt_scene_t *s) {
                           &ds->probes, &ds->stats})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
+        for (auto &t : ds->tile_orders) t->buf.release();
         if (ds->stream) (void)hipStreamDestroy(ds->stream);
     }
     delete s;
@@ -753,6 +796,7 @@ int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format 
     job.cam_buf = nullptr;
     job.stream = ds->stream;
     job.stats = stats;
+    job.strict = opts && opts->strict_reference;
     // abort is polled between slab launches (the reference polls per pixel, render.cpp:412)
     const int slab = abort_flag ? std::max(64, (b.owned_rows + 7) / 8 / 16 * 16) : b.owned_rows;
     bool aborted = false;
@@ -801,6 +845,7 @@ int nt_render_device(nt_scene_t *s, void *dest_dev, size_t dest_len, const nt_im
     job.nframes = 1;
     job.stream = (hipStream_t)hip_stream;
     job.stats = stats;
+    job.strict = opts && opts->strict_reference;
     job.row_begin = 0;
     job.row_count = b.owned_rows;
     return enqueue(s, ds, job);
@@ -843,6 +888,7 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     job.cam_buf = (const float *)ds->cams.p;
     job.stream = (hipStream_t)hip_stream;
     job.stats = stats;
+    job.strict = opts && opts->strict_reference;
     job.row_begin = 0;
     job.row_count = b.owned_rows;
     return enqueue(s, ds, job);

@@ -93,6 +93,7 @@ struct NtCompositeDev {
     int all_opaque;           // every material has opacity >= 1
     int any_reflective;
     int has_scalar_prims;     // leaves hold unbatched triangles or solids
+    int prune;                // 1: closest-hit walks drop subtrees that start clearly beyond the current hit (nt_beyond_hit)
     unsigned long long *stats;  // nullptr or 8 counters (nt_stats order)
 };
 
@@ -107,6 +108,7 @@ struct NtLaunchInfo {
     const float *persist_cams;
     int cu_count;
     int kernel_choice;        // 0: default (packet kernel for lean scenes), 1: persistent per-lane kernel, 2: tile kernel
+    const int *tile_order;    // packet kernel: device permutation of the 16x16-pixel quads of the launch (or nullptr)
 };
 
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);

@@ -758,6 +758,17 @@ __device__ __forceinline__ bool leaf_closest(const NtCompositeDev &sc, const Wav
 //   - `(hit && o_hit.dist <= t) || !n_far` => the frame returns (pop again), otherwise continue into far
 //     with t_near = t; far == -1 encodes the `!n_far` case so that t_far is always the top entry's t.
 // split distance of branch `nd` for the ray in the table: (split - origin[axis]) * invdir[axis] (tracer.hpp:1197)
+// Not in the reference: its closest-hit walk (tracer.hpp:1179-1243) only stops at a branch when the NEAR subtree
+// itself reported the hit (`hit && o_hit.dist <= t`, :1213); a ray whose hit was found in a leaf that ends before
+// the hit point keeps descending into every later cell up to the far end of the scene (on the 120-cell: up to
+// 2 900 of the 3 600 batches per ray).  A cell whose interval starts beyond the current hit cannot hold a
+// closer one as long as every primitive is listed in each cell it overlaps -- the invariant the reference's own
+// early exit relies on -- so such subtrees are dropped; the margin keeps cells that start within rounding
+// distance of the hit (primitives embedded in a split plane, :1217-1222).  Off with nt_render_opts.strict_reference.
+__device__ __forceinline__ bool nt_beyond_hit(float hit_dist, float t_near) {
+    return hit_dist < t_near - 1e-4f * (1.0f + fabsf(t_near));
+}
+
 __device__ __forceinline__ float branch_t(const WaveLds &w, int lane, const NtNode &nd, bool &gt) {
     const float2 oi = w.ray[nd.axis * 64 + lane];
     gt = oi.x > nd.split;
@@ -778,6 +789,7 @@ __device__ __forceinline__ bool trace_closest(const NtCompositeDev &sc, const Wa
     const int max_sp = sc.stack_depth;
     for (;;) {
         while (node >= 0) {
+            if (sc.prune && nt_beyond_hit(hit.dist, t_near)) { node = -1; break; }
             const NtNode nd = sc.nodes[node];
             if (nd.axis < 0) {
                 if (STATS) st.leaves += 1;
@@ -1040,12 +1052,36 @@ struct Level {      // one frame of the base_color/ray_color recursion that is w
 };
 
 // ray_color's miss branch (tracer.hpp:1866-1867)
+// v[idx] for a wave-uniform idx without indexing registers: a chain of v_cndmask on uniform masks, spelled in asm
+// because LLVM folds the equivalent C select chain back into an indexed array, which lands in scratch memory
+// (a vector-memory round trip per use, and scratch-using waves are admitted at half the occupancy).
+template <int N>
+__device__ __forceinline__ float pick_uniform(const float (&v)[N], int idx) {
+    const int u = __builtin_amdgcn_readfirstlane(idx);
+    float r = v[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) {
+        const unsigned long long is_k = __builtin_amdgcn_ballot_w64(u == k);
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(r), "v"(v[k]), "s"(is_k));
+    }
+    return r;
+}
+
+// v[idx] for a per-lane idx, same idea (the masks come from v_cmp through ballot)
+template <int N>
+__device__ __forceinline__ float pick_lane(const float (&v)[N], int idx) {
+    float r = v[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) {
+        const unsigned long long is_k = __builtin_amdgcn_ballot_w64(idx == k);
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(r), "v"(v[k]), "s"(is_k));
+    }
+    return r;
+}
+
 template <int N>
 __device__ __forceinline__ Color3 background_color(const NtCompositeDev &sc, const float (&d)[N]) {
-    // target.direction[bg_gradient_axis]: select chain instead of indexing registers
-    float iv = d[0];
-#pragma unroll
-    for (int k = 1; k < N; ++k) iv = sc.bg_axis == k ? d[k] : iv;
+    const float iv = pick_uniform<N>(d, sc.bg_axis);          // target.direction[bg_gradient_axis]
     return iv >= 0.0f ? cadd(cscale(c3p(sc.bg1), iv), cscale(c3p(sc.bg2), 1.0f - iv))
                       : cadd(cscale(c3p(sc.bg3), -iv), cscale(c3p(sc.bg2), 1.0f + iv));
 }
@@ -1812,6 +1848,7 @@ __global__ __launch_bounds__(64) void composite_kernel_var(NtCamera cam, NtCompo
         float t_near = dist0, t_far = FLT_MAX;
         for (;;) {
             while (node >= 0) {
+                if (sc.prune && nt_beyond_hit(hit.dist, t_near)) { node = -1; break; }
                 const NtNode nd = sc.nodes[node];
                 if (nd.axis < 0) {
                     bool improved = false;
@@ -2122,6 +2159,7 @@ __global__ __launch_bounds__(256) void composite_persistent(NtCompositeDev sc, N
                 node = -1;
             }
             if (node >= 0) {
+                if (sc.prune && nt_beyond_hit(hit.dist, t_near)) { node = -1; continue; }
                 const NtNode nd = sc.nodes[node];
                 if (nd.axis < 0) {
                     in_leaf = true;
@@ -2203,29 +2241,52 @@ __global__ __launch_bounds__(256) void composite_persistent(NtCompositeDev sc, N
 // mask plus each lane's (t_split, t_far) pair.
 struct PacketArgs {
     const float *cams;        // [frame][4][N]
-    int tiles_x;
+    const int *order;         // nullptr, or a permutation of the quads (2x2 tiles): expensive (central) rows first
+    int tiles_x, tiles_y;
+    int quads_x;
+    int quads;                // quads per frame
+    int nframes;
+    int lds_per_wave;         // bytes
+    int frame_major;          // work items numbered frame-major instead of quad-rank-major
 };
 
-// The per-lane part of the frame stack, (t_split | NaN = far-only, t_far to restore), lives in VGPRs: the
-// stack pointer is wave-uniform, so the arrays are indexed through M0 (s_set_gpr_idx), not spilled.  The ray's
-// origin / inverse direction are indexed the same way by the (uniform) split axis.  LDS only holds the
-// mailbox and the uniform (far node, lane mask) pairs, which keeps ~20 waves per CU resident.
+// The per-lane part of the frame stack is ONE register: bit k of `bothbits` says that the lane entered both
+// sides of the branch pushed at level k.  The split distances the reference keeps in its recursion frames
+// (t for the far call, t_far to restore) are recomputed from the level's (split, axis) when a frame is
+// resumed -- same operands and operations, so the same floats -- which keeps the kernel under 64 VGPRs (a
+// per-level float array cost 28 and held the kernel at 4 waves per SIMD).  LDS holds the mailbox and the
+// uniform per-level record (far node, far-lane mask, split, axis).
 // FEAT = true: the packet walk finds the primary hits (batches only), then every lane shades its hit with the
 // general base_color -- lights, shadow rays (per-lane _occludes walks), reflections (per-lane closest-hit walks);
 // those secondary walks need the per-lane LDS stack + ray table, placed after the packet's own LDS.
+// A 256-thread block is four independent waves (no barrier) rendering a 2x2 quad of 8x8 tiles of one frame:
+// neighbouring rays walk the same leaves, so the four waves share what their scalar loads bring into the CU's
+// scalar cache (blocks of unrelated tiles ran ~12 % slower).  Quads are dispatched through a host table: quad
+// rows nearest the image centre first (they hold the long walks), row-major within a row.
 template <int N, int DEPTH, bool FEAT>
-__global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarget tg, PacketArgs pa) {
+__global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtCompositeDev sc, NtTarget tg, PacketArgs pa) {
     extern __shared__ float2 lds_raw[];
-    const int lane = (int)threadIdx.x;
+    const int lane = (int)threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#ifdef NT_EXP_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
+    const long long slot = (long long)blockIdx.x;
+    int rank, frame;
+    if (pa.frame_major) { frame = (int)(slot / pa.quads); rank = (int)(slot - (long long)frame * pa.quads); }
+    else { rank = (int)(slot / pa.nframes); frame = (int)(slot - (long long)rank * pa.nframes); }
+    float2 *lds_wave = reinterpret_cast<float2 *>(reinterpret_cast<char *>(lds_raw) + (size_t)wv * pa.lds_per_wave);
     WaveLds w;              // view used by the shared helpers (mailbox; FEAT: also ray table and per-lane stack)
-    w.ray = lds_raw;                                                       // [N][64] float2 (FEAT only)
-    w.stack = reinterpret_cast<int *>(lds_raw + (FEAT ? 64 * N : 0));     // [stack_depth][64] (FEAT only)
+    w.ray = lds_wave;                                                      // [N][64] float2 (FEAT only)
+    w.stack = reinterpret_cast<int *>(lds_wave + (FEAT ? 64 * N : 0));    // [stack_depth][64] (FEAT only)
     w.mbox = w.stack + (FEAT ? 64 * sc.stack_depth : 0);
-    int *ustack = w.mbox + 64 * NT_MBOX;          // [DEPTH][4]: far node, mask lo, mask hi, -
+    int *ustack = w.mbox + 64 * NT_MBOX;          // [DEPTH][8]: far node, far-lane mask lo, hi, split, axis
 
     // ---- this wave's tile
-    const int tile = (int)blockIdx.x;
-    const int ty = tile / pa.tiles_x, tx = tile - ty * pa.tiles_x;
+    const int quad = pa.order ? pa.order[rank] : rank;
+    const int qy = quad / pa.quads_x, qx = quad - qy * pa.quads_x;
+    const int tx = qx * 2 + (wv & 1), ty = qy * 2 + (wv >> 1);
+    if (tx >= pa.tiles_x || ty >= pa.tiles_y) return;
     const int x = tx * 8 + (lane & 7);
     const int row = ty * 8 + (lane >> 3);
     bool valid = x < tg.width && row < tg.row_count;
@@ -2236,11 +2297,11 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
         y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
     }
     valid = valid && y < tg.height;
-    const long long out_off = (long long)blockIdx.y * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+    const long long out_off = (long long)frame * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
 
     float o[N], d[N], invd[N];
     {
-        const float *c = pa.cams + (size_t)blockIdx.y * 4 * N;
+        const float *c = pa.cams + (size_t)frame * 4 * N;
         float right[N], up[N], fwd[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) { o[k] = c[k]; right[k] = c[N + k]; up[k] = c[2 * N + k]; fwd[k] = c[3 * N + k]; }
@@ -2255,13 +2316,14 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
     bool active = valid && dist0 >= 0.0f;
     float t_near = dist0, t_far = FLT_MAX;
     int dirty = 0;
-    float st_t[DEPTH];       // per level: this lane's split distance if it entered BOTH sides there, else NaN
+    unsigned int bothbits = 0u;   // bit k: this lane entered BOTH sides of the branch pushed at stack level k
     mbox_reset(w, lane);
 
     int node = sc.root;      // wave-uniform
     int sp = 0;              // wave-uniform
     for (;;) {
         while (node >= 0) {
+            if (sc.prune) active = active && !nt_beyond_hit(hit.dist, t_near);
             if (__builtin_amdgcn_ballot_w64(active) == 0ull) { node = -1; break; }
             const NtNode nd = sc.nodes[node];                // uniform address -> scalar load
             if (nd.axis < 0) {
@@ -2334,10 +2396,11 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
                 break;
             }
             // ---- branch: kd_node_intersection::operator() (tracer.hpp:1189-1240)
-            const int axis = nd.axis;                          // uniform: select chains, no indexed access
-            float oa = o[0], inv = invd[0];                    // oa is the same in every lane (shared origin)
+            const int axis = __builtin_amdgcn_readfirstlane(nd.axis);      // uniform
+            float oa = o[0];                                   // the same in every lane (shared origin)
 #pragma unroll
-            for (int k = 1; k < N; ++k) { oa = axis == k ? o[k] : oa; inv = axis == k ? invd[k] : inv; }
+            for (int k = 1; k < N; ++k) oa = axis == k ? o[k] : oa;
+            const float inv = pick_uniform<N>(invd, axis);
             const bool gt = __builtin_amdgcn_readfirstlane((int)(oa > nd.split)) != 0;
             const int n_near = gt ? nd.right : nd.left;
             const int n_far = gt ? nd.left : nd.right;
@@ -2369,11 +2432,13 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
             if (m_near != 0ull) {
                 if (m_far != 0ull && sp < DEPTH) {
                     if (lane == 0) {
-                        ustack[sp * 4 + 0] = n_far;
-                        ustack[sp * 4 + 1] = (int)(unsigned int)(m_far & 0xffffffffull);
-                        ustack[sp * 4 + 2] = (int)(unsigned int)(m_far >> 32);
+                        ustack[sp * 8 + 0] = n_far;
+                        ustack[sp * 8 + 1] = (int)(unsigned int)(m_far & 0xffffffffull);
+                        ustack[sp * 8 + 2] = (int)(unsigned int)(m_far >> 32);
+                        ustack[sp * 8 + 3] = __float_as_int(nd.split);
+                        ustack[sp * 8 + 4] = axis;
                     }
-                    st_t[sp] = both ? t : __int_as_float(0x7fc00000);
+                    bothbits = both ? (bothbits | (1u << sp)) : (bothbits & ~(1u << sp));
                     ++sp;
                 }
                 if (both && near_lane) t_far = t;
@@ -2390,22 +2455,33 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
         // ---- the frame returned: resume the innermost pending far side
         if (sp == 0) break;
         --sp;
-        const int far = __builtin_amdgcn_readfirstlane(ustack[sp * 4 + 0]);
-        const unsigned long long m = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 4 + 2]) << 32) |
-                                     (unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 4 + 1]);
-        const float et = st_t[sp];
+        const int far = __builtin_amdgcn_readfirstlane(ustack[sp * 8 + 0]);
+        const unsigned long long m = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 8 + 2]) << 32) |
+                                     (unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 8 + 1]);
+        const bool was_both = ((bothbits >> sp) & 1u) != 0u;
         const bool near_hit = sp < dirty;
         if (dirty > sp) dirty = sp;
         bool join = ((m >> lane) & 1ull) != 0ull;
-        if (__builtin_amdgcn_ballot_w64(join && et == et) != 0ull) {
-            // t_far of the frame being resumed = the split of the innermost pending branch below that this lane
-            // entered on both sides (its near subtree is where we are); none: the root's t_far
+        if (__builtin_amdgcn_ballot_w64(join && was_both) != 0ull) {
+            // the split distance of the branch being resumed, recomputed from its (split, axis): same operands,
+            // same operations as at the push, hence the same float
+            const float psplit = __int_as_float(__builtin_amdgcn_readfirstlane(ustack[sp * 8 + 3]));
+            const int paxis = __builtin_amdgcn_readfirstlane(ustack[sp * 8 + 4]);
+            float poa = o[0];
+#pragma unroll
+            for (int k = 1; k < N; ++k) poa = paxis == k ? o[k] : poa;
+            const float et = (psplit - poa) * pick_uniform<N>(invd, paxis);
+            // t_far of the frame being resumed = the split distance of the innermost pending branch below that this
+            // lane entered on both sides (its near subtree is where we are); none: the root's t_far
+            const unsigned int below = bothbits & ((1u << sp) - 1u);
             float ef = FLT_MAX;
-            for (int k = 0; k < sp; ++k) {
-                const float v = st_t[k];
-                ef = v == v ? v : ef;
+            if (below != 0u) {
+                const int ks = 31 - __clz((int)below);
+                const float s2 = __int_as_float(ustack[ks * 8 + 3]);
+                const int a2 = ustack[ks * 8 + 4];
+                ef = (s2 - pick_lane<N>(o, a2)) * pick_lane<N>(invd, a2);
             }
-            if (join && et == et) {                        // a `both` lane: (hit && o_hit.dist <= t) -> return
+            if (join && was_both) {                        // a `both` lane: (hit && o_hit.dist <= t) -> return
                 if (near_hit && hit.dist <= et) join = false;
                 else { t_near = et; t_far = ef; }
             }
@@ -2414,6 +2490,16 @@ __global__ __launch_bounds__(64) void composite_packet(NtCompositeDev sc, NtTarg
         node = far;
     }
 
+#ifdef NT_EXP_TRACE
+    if (lane == 0) {       // ablation builds only: per-wave residency record behind the last frame
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(tg.dest + (long long)pa.nframes * tg.frame_stride) +
+                                 ((size_t)frame * pa.tiles_x * pa.tiles_y + (size_t)ty * pa.tiles_x + tx) * 4;
+        tr[0] = trace_t0;
+        tr[1] = wall_clock64();
+        tr[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+        tr[3] = __builtin_amdgcn_ballot_w64(hit.item >= 0);
+    }
+#endif
     if (valid) {
         Color3 c;
         if (FEAT) {
@@ -2486,23 +2572,25 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
         PacketArgs pk;
         pk.cams = li.persist_cams;
         pk.tiles_x = (tg.width + 7) / 8;
-        const int tiles = pk.tiles_x * ((tg.row_count + 7) / 8);
-        const dim3 pgrid((unsigned)tiles, (unsigned)li.nframes);
+        pk.tiles_y = (tg.row_count + 7) / 8;
+        pk.quads_x = (pk.tiles_x + 1) / 2;
+        pk.quads = pk.quads_x * ((pk.tiles_y + 1) / 2);
+        pk.nframes = li.nframes;
+        pk.order = li.tile_order;
+        pk.frame_major = getenv("NTRACER_FRAME_MAJOR") ? atoi(getenv("NTRACER_FRAME_MAJOR")) : 1;
+        const dim3 pgrid((unsigned)((long long)pk.quads * li.nframes));
 #define NT_PACKET_CASE(D)                                                                                   \
     if (sc.stack_depth <= D) {                                                                              \
         if (feat) {                                                                                         \
-            const size_t plds = (size_t)64 * ((size_t)N * 8 + (size_t)sc.stack_depth * 4 + NT_MBOX * 4) + (size_t)D * 16; \
-            hipLaunchKernelGGL((composite_packet<N, D, true>), pgrid, dim3(64), plds, s, sc, tg, pk);       \
+            pk.lds_per_wave = (int)((size_t)64 * ((size_t)N * 8 + (size_t)sc.stack_depth * 4 + NT_MBOX * 4) + (size_t)D * 32); \
+            hipLaunchKernelGGL((composite_packet<N, D, true>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, tg, pk); \
         } else {                                                                                            \
-            const size_t plds = (size_t)64 * NT_MBOX * 4 + (size_t)D * 16;                                  \
-            hipLaunchKernelGGL((composite_packet<N, D, false>), pgrid, dim3(64), plds, s, sc, tg, pk);      \
+            pk.lds_per_wave = (int)((size_t)64 * NT_MBOX * 4 + (size_t)D * 32);                             \
+            hipLaunchKernelGGL((composite_packet<N, D, false>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, tg, pk); \
         }                                                                                                   \
         return 0;                                                                                           \
     }
-        NT_PACKET_CASE(12)
-        NT_PACKET_CASE(20)
-        NT_PACKET_CASE(28)
-        NT_PACKET_CASE(32)
+        NT_PACKET_CASE(32)        // DEPTH only sizes the per-level LDS records (32 B each)
 #undef NT_PACKET_CASE
     }
     if (!feat && !sc.stats && !tg.colors_out && li.persist_counter) {

@@ -6,6 +6,7 @@ HIP kernels -- see include/ntracer_hip.h.  Types outside the path (pickling,
 capsules) are intentionally absent.
 """
 import ctypes as C
+import os
 import threading
 
 from . import _lib
@@ -267,14 +268,17 @@ def _host_buffer(dest):
     return arr, n
 
 
-def _opts(device=-1, band_rank=0, band_world=1, compact=False, collect_stats=False, band_rows=0):
+def _opts(device=-1, band_rank=0, band_world=1, compact=False, collect_stats=False, band_rows=0, strict_reference=None):
     o = _lib.NtRenderOpts()
     o.device = device
     o.band_rank = band_rank
     o.band_world = band_world
     o.band_rows = band_rows
     o.compact = 1 if compact else 0
-    o.strict_reference = 1
+    # None: follow NTRACER_STRICT_REFERENCE (default 0 = skip k-d cells beyond the current hit; same pixels)
+    if strict_reference is None:
+        strict_reference = os.environ.get("NTRACER_STRICT_REFERENCE", "0") not in ("", "0")
+    o.strict_reference = 1 if strict_reference else 0
     o.collect_stats = 1 if collect_stats else 0
     return o
 
@@ -293,7 +297,7 @@ class BlockingRenderer(object):
         self._mut = threading.Lock()
         self._busy = False
 
-    def render(self, dest, format, scene, band_rank=0, band_world=1, compact=False, collect_stats=False):
+    def render(self, dest, format, scene, band_rank=0, band_world=1, compact=False, collect_stats=False, strict_reference=None):
         if not isinstance(format, ImageFormat):
             raise TypeError("format must be an ImageFormat")
         if not isinstance(scene, Scene):
@@ -309,12 +313,12 @@ class BlockingRenderer(object):
             L = _lib.lib()
             if dev is not None:
                 ptr, nbytes, index, stream = dev
-                opts = _opts(index, band_rank, band_world, compact, collect_stats)
+                opts = _opts(index, band_rank, band_world, compact, collect_stats, strict_reference=strict_reference)
                 _lib.check(L.nt_render_device(scene._handle, C.c_void_p(ptr), nbytes, C.byref(fmt), C.byref(opts),
                                               C.c_void_p(stream)))
                 return True
             arr, n = _host_buffer(dest)
-            opts = _opts(self.device, band_rank, band_world, compact, collect_stats)
+            opts = _opts(self.device, band_rank, band_world, compact, collect_stats, strict_reference=strict_reference)
             r = _lib.check(L.nt_render(scene._handle, arr, n, C.byref(fmt), C.byref(opts), C.byref(self._abort)))
             return r != _lib.NT_ABORTED
         finally:

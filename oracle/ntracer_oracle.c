@@ -423,6 +423,9 @@ typedef struct {
 static int kd_visit(kd_isect_t *k, int node, float t_near, float t_far) {
     const nto_scene *s = k->cx->s;
     while (node >= 0) {
+        /* optional (NOT in the reference; see nto_scene.prune_beyond_hit): a cell that begins clearly beyond
+           the nearest hit so far cannot hold a closer one */
+        if (s->prune_beyond_hit && k->o_hit->dist < t_near - 1e-4f * (1.0f + fabsf(t_near))) return 0;
         int axis = s->node_axis[node];
         if (axis < 0) return leaf_intersects(k->cx, node, k->target, k->skip, k->o_hit, k->t_hits, &k->checked);
         if (k->cx->c) k->cx->c->branches++;

@@ -34,7 +34,7 @@ class Scene(C.Structure):
         ("bg_gradient_axis", C.c_int32),
         ("ambient", C.c_float * 3), ("bg1", C.c_float * 3), ("bg2", C.c_float * 3), ("bg3", C.c_float * 3),
         ("n_point_lights", C.c_int32), ("pl_pos", f32p), ("pl_color", f32p),
-        ("n_global_lights", C.c_int32), ("gl_dir", f32p), ("gl_color", f32p), ("clean_normals", C.c_int32)]
+        ("n_global_lights", C.c_int32), ("gl_dir", f32p), ("gl_color", f32p), ("clean_normals", C.c_int32), ("prune_beyond_hit", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -84,10 +84,11 @@ def _i(a):
 class OracleScene:
     """Owns numpy copies of every array and exposes the nto_scene struct."""
 
-    def __init__(self, n, origin, axes, fov=0.8, flat=None, params=None, clean_normals=False):
+    def __init__(self, n, origin, axes, fov=0.8, flat=None, params=None, clean_normals=False, prune=False):
         self._keep = {}
         s = Scene()
         s.clean_normals = 1 if clean_normals else 0
+        s.prune_beyond_hit = 1 if prune else 0
         s.n = int(n)
         s.fov = float(fov)
         self.n = int(n)

@@ -248,18 +248,59 @@ def test_cell120_full_size_properties_and_counters():
     assert np.array_equal(fb[0].cpu().numpy().reshape(h, fmt.pitch), img)
     sc._set_camera_arrays(g["origins"][52], g["axes"][52])
     assert np.array_equal(fb[1].cpu().numpy().reshape(h, fmt.pitch), render_host(sc, fmt))
-    # counters: same tree walk as the oracle (branches/leaves identical; the device has no mailbox, so it
-    # tests at least as many simplices)
+    # counters: same tree walk as the oracle (branches/leaves identical; the device's mailbox is small, so it
+    # tests at least as many simplices) -- for the reference's exact walk (strict) and for the default walk that
+    # drops cells beyond the current hit
     sc._set_camera_arrays(g["origins"][0], g["axes"][0])
     lat = fmt_of(w, h, fx.RGBX8)
-    render_host(sc, lat, collect_stats=True)
-    st = sc.last_stats()
-    _, oc = ob.OracleScene(4, g["origins"][0], g["axes"][0], flat=flat).colors_at(g["xs"], g["ys"], w, h, counters=True)
     per = lambda d, k: d[k] / d["rays"]
-    assert abs(per(st, "branches") - per(oc, "branches")) < 0.05 * per(oc, "branches")
-    assert abs(per(st, "leaves") - per(oc, "leaves")) < 0.05 * per(oc, "leaves")
-    assert abs(per(st, "hits") - per(oc, "hits")) < 0.02
-    assert per(st, "simplex_tests") >= 0.95 * per(oc, "simplex_tests")
+    walks = {}
+    for strict in (True, False):
+        img0 = render_host(sc, lat, collect_stats=True, strict_reference=strict)
+        st = sc.last_stats()
+        _, oc = ob.OracleScene(4, g["origins"][0], g["axes"][0], flat=flat, prune=not strict).colors_at(g["xs"], g["ys"], w, h, counters=True)
+        assert abs(per(st, "branches") - per(oc, "branches")) < 0.05 * per(oc, "branches")
+        assert abs(per(st, "leaves") - per(oc, "leaves")) < 0.05 * per(oc, "leaves")
+        assert abs(per(st, "hits") - per(oc, "hits")) < 0.02
+        assert per(st, "simplex_tests") >= 0.95 * per(oc, "simplex_tests")
+        walks[strict] = (img0, per(st, "simplex_tests"))
+    assert np.array_equal(walks[True][0], walks[False][0])
+    assert walks[False][1] < walks[True][1]
+
+
+def test_pruned_walk_renders_the_reference_walks_bytes():
+    """The default closest-hit walk skips k-d cells that begin beyond the current hit (nt_beyond_hit); with
+    strict_reference the kernels visit exactly the cells the reference visits.  Same bytes, on every kernel:
+    120-cell frames where the reference's walk runs on to the far end of the scene for the central rays (packet
+    kernel), the lit / reflective variant (packet + per-lane secondary rays), and the mixed feature scene (tile
+    kernel with solids and loose triangles)."""
+    g = fx.load("cell120_n4")
+    sc = tracern.CompositeScene.from_flat(4, fx.flat_of(g))
+    fmt = fmt_of(1920, 1080, fx.RGBX8)
+    for f in (40, 120):
+        sc._set_camera_arrays(g["origins"][f], g["axes"][f])
+        assert np.array_equal(render_host(sc, fmt, strict_reference=True), render_host(sc, fmt, strict_reference=False))
+    g = fx.load("cell600_n4")
+    flat = fx.flat_of(g)
+    m = np.array(flat["materials"], np.float32).copy()
+    m[:, 7] = 0.3
+    flat["materials"] = m
+    sc = tracern.CompositeScene.from_flat(4, flat)
+    sc.set_params_flat(dict(fov=0.8, shadows=1, camera_light=1, max_reflect_depth=2, bg_gradient_axis=1,
+                            ambient=[.02, .02, .03], bg1=[1, 1, 1], bg2=[0, 0, 0], bg3=[0, 1, 1],
+                            point_light_pos=[[20.0, 15.0, -25.0, 5.0]], point_light_color=[[900.0, 800.0, 700.0]],
+                            global_light_dir=[[0.2, -0.9, 0.3, 0.1]], global_light_color=[[.4, .4, .5]]))
+    sc._set_camera_arrays(g["origins"][5], g["axes"][5])
+    fmt = fmt_of(480, 270, fx.RGBF32)
+    assert np.array_equal(render_host(sc, fmt, strict_reference=True), render_host(sc, fmt, strict_reference=False))
+    g = fx.load("feature3d")
+    flat = fx.flat_of(g, opaque=True)                  # transparency always walks strictly
+    for v in g["variants"]:
+        sc = tracern.CompositeScene.from_flat(3, flat)
+        sc.set_params_flat(fx.params_of(g, "%s__" % v))
+        sc._set_camera_arrays(g["origin"], g["axes"])
+        fmt = fmt_of(320, 240, fx.RGBF32)
+        assert np.array_equal(render_host(sc, fmt, strict_reference=True), render_host(sc, fmt, strict_reference=False))
 
 
 def test_three_composite_kernels_render_identical_frames(monkeypatch):

@@ -178,3 +178,32 @@ def test_threaded_render_is_deterministic():
     a = sc.render(97, 65, fx.RGB16, threads=0)
     b = sc.render(97, 65, fx.RGB16, threads=5)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["cell600_n4", "orthoplex5_n5", "simplex10_n10"])
+def test_pruned_walk_is_pixel_identical_on_the_oracle(name):
+    """nto_scene.prune_beyond_hit (what the HIP kernels do unless strict_reference is set) against the
+    reference's walk: same packed frame, fewer batch tests."""
+    g = fx.load(name)
+    n = int(g["dimension"])
+    flat = fx.flat_of(g)
+    f = int(g["frames"][1])
+    res = []
+    for prune in (False, True):
+        buf, cnt = ob.OracleScene(n, g["origins"][f], g["axes"][f], flat=flat, prune=prune).render(160, 90, fx.RGBF32, threads=4, counters=True)
+        res.append((buf, cnt))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert res[1][1]["batch_tests"] <= res[0][1]["batch_tests"]
+    assert res[1][1]["leaves"] <= res[0][1]["leaves"]
+
+
+def test_pruned_walk_identical_on_the_feature_scene():
+    g = fx.load("feature3d")
+    flat = fx.flat_of(g)
+    w, h = int(g["width"]), int(g["height"])
+    flat = fx.flat_of(g, opaque=True)                  # transparency always walks strictly
+    for v in g["variants"]:
+        p = fx.params_of(g, "%s__" % v)
+        a = ob.OracleScene(3, g["origin"], g["axes"], flat=flat, params=p, clean_normals=True).render(w, h, fx.RGBF32, threads=4)
+        b = ob.OracleScene(3, g["origin"], g["axes"], flat=flat, params=p, clean_normals=True, prune=True).render(w, h, fx.RGBF32, threads=4)
+        assert np.array_equal(a, b), v
