@@ -265,22 +265,36 @@ __device__ __forceinline__ void primary_dir(const NtTarget &tg, const float (&ri
 //      mu = 1e-4*(1+|o_K|) -- ~100x the rounding error of the quantities compared and of the reference's
 //      check.  Only the remaining near-ties (normally just K) get the division and the N-1 checks, in
 //      ascending order, exactly as the reference computes them.
+// Step 1 of the pruning above, on the UNNORMALISED direction v (|v|^2 = sq): the ray passes within the
+// circumradius unless |o|^2 - (o.v)^2/|v|^2 > rad2.  Conservative (0.1 % on the radius, 1e-4 on the product),
+// not bit-exact -- it only decides whether the exact predicate is evaluated at all.  Waves in which no lane
+// may hit never normalise more than dir[0], the one component the background colour needs: that saves N-1 of
+// the N IEEE divisions for ~85 % of the rays of the 6-D benchmark frames.
 template <int N>
-__device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir)[N], float &r, float &g, float &b) {
+__device__ __forceinline__ bool box_may_hit(const float (&o)[N], const float (&v)[N], float sq) {
+    float osq = o[0] * o[0], ov = o[0] * v[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) { osq += o[j] * o[j]; ov += o[j] * v[j]; }
+    const float rad2 = (float)N * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
+#ifdef NT_EXP_SKIP_SLABS
+    return false;
+#else
+    return !((osq - rad2) * sq > ov * ov * 1.0001f);         // NaN -> maybe
+#endif
+}
+
+__device__ __forceinline__ void box_background(float in, float &r, float &g, float &b) {
+    // miss: i = dir[0]; i > 0 ? (i,i,i) : (0,-i,-i)   (tracer.hpp:109-113)
+    if (in > 0.0f) { r = in; g = in; b = in; }
+    else { r = 0.0f; g = -in; b = -in; }
+}
+
+template <int N>
+__device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir)[N], bool maybe, float &r, float &g, float &b) {
     bool done = false;     // a face passed the slab test (hit, or dist >= cutoff)
     float shade = 0.0f;
 
-    float osq = o[0] * o[0], od = o[0] * dir[0];
-#pragma unroll
-    for (int j = 1; j < N; ++j) { osq += o[j] * o[j]; od += o[j] * dir[j]; }
-    const float rad2 = (float)N * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
-#ifdef NT_EXP_SKIP_SLABS
-    const bool maybe = false;
-#else
-    const bool maybe = !((osq - od * od) > rad2);            // NaN -> maybe
-#endif
-
-    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+    {
         float num[N];
         bool pre[N];
         // candidates: dist > 0 needs a non-zero numerator with the sign of d_i; track the last-reached one
@@ -330,9 +344,7 @@ __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir
         g = shade * 0.5f;
         b = shade * 0.5f;
     } else {
-        const float in = dir[0];
-        if (in > 0.0f) { r = in; g = in; b = in; }
-        else { r = 0.0f; g = -in; b = -in; }
+        box_background(dir[0], r, g, b);
     }
 }
 
@@ -343,9 +355,24 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
     if (!pr.valid) return;
     float org[N], right[N], up[N], fwd[N], dir[N];
     load_camera<N>(cam, org, right, up, fwd);
-    primary_dir<N>(tg, right, up, fwd, pr.x, pr.y, dir);
+    // flat_origin_ray_source::operator() (tracer.hpp:71-75), as primary_dir, with the normalisation split off
+    const float sx = tg.fovI * ((float)pr.x - tg.half_w);
+    const float sy = tg.fovI * ((float)pr.y - tg.half_h);
+#pragma unroll
+    for (int j = 0; j < N; ++j) dir[j] = (fwd[j] + right[j] * sx) - up[j] * sy;
+    float sq = dir[0] * dir[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+    const float len = sqrtf(sq);
+    const bool maybe = box_may_hit<N>(org, dir, sq);
     float r, g, b;
-    box_color<N>(org, dir, r, g, b);
+    if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) {
+        box_background(dir[0] / len, r, g, b);
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) dir[j] = dir[j] / len;
+        box_color<N>(org, dir, maybe, r, g, b);
+    }
     emit_pixel(tg, pr, r, g, b);
 }
 
@@ -377,21 +404,27 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
         sq = j == 0 ? v * v : sq + v * v;
     }
     const float len = sqrtf(sq);
-    for (int j = 0; j < n; ++j) dir[j * 256] = dir[j * 256] / len;
 
     bool done = false;
     float shade = 0.0f;
-    // Same exact pruning as box_color<N> (see there): circumsphere rejection per wave, then only the faces in
-    // a near-tie with the last-reached candidate K get the division and the n-1 checks.
-    float osq = 0.0f, od = 0.0f;
+    // Same exact pruning as box_color<N> (see there): circumsphere rejection per wave on the unnormalised
+    // direction (box_may_hit), then only the faces in a near-tie with the last-reached candidate K get the
+    // division and the n-1 checks.  Waves that cannot hit normalise dir[0] only.
+    float osq = 0.0f, ov = 0.0f;
     for (int j = 0; j < n; ++j) {
         const float oj = c[j];
         osq = fmaf(oj, oj, osq);
-        od = fmaf(oj, dir[j * 256], od);
+        ov = fmaf(oj, dir[j * 256], ov);
     }
     const float rad2 = (float)n * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
-    const bool maybe = !((osq - od * od) > rad2 * 1.0001f + 1e-5f * osq);       // FMA rounding covered by the margin
-    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+    const bool maybe = !((osq - rad2 * 1.0001f - 1e-5f * osq) * sq > ov * ov * 1.0001f);   // FMA rounding covered by the margins
+    const bool wave_maybe = __builtin_amdgcn_ballot_w64(maybe) != 0ull;
+    if (wave_maybe) {
+        for (int j = 0; j < n; ++j) dir[j * 256] = dir[j * 256] / len;
+    } else {
+        dir[0] = dir[0] / len;
+    }
+    if (wave_maybe) {
         float aK = 0.0f, bK = 1.0f, oK = 0.0f;
         bool any = false;
         for (int i = 0; i < n; ++i) {
@@ -2259,6 +2292,33 @@ struct PacketArgs {
 // FEAT = true: the packet walk finds the primary hits (batches only), then every lane shades its hit with the
 // general base_color -- lights, shadow rays (per-lane _occludes walks), reflections (per-lane closest-hit walks);
 // those secondary walks need the per-lane LDS stack + ray table, placed after the packet's own LDS.
+// Wave-level mailbox of the packet kernel: the walk is wave-uniform, so "which lanes have already tested batch X"
+// is one 64-bit mask per batch.  NT_WM direct-mapped entries (tag, mask) replace the per-lane 16-slot mailbox: the
+// lookup is one LDS read of a uniform address, and 256 entries remember a ray's whole path through all but the
+// largest leaves (the reference keeps every tested primitive in `checked`, tracer.hpp:1166; forgetting one only
+// costs a repeated test, which cannot change the hit).  wm_claim returns whether this lane still has to test
+// `item` and records that it will.
+#define NT_WM 256
+__device__ __forceinline__ void wm_reset(int *wm, int lane) {
+#pragma unroll
+    for (int k = 0; k < NT_WM / 64; ++k) wm[(k * 64 + lane) * 4] = -1;
+}
+__device__ __forceinline__ bool wm_claim(int *wm, int lane, int item, bool active) {
+    int *e = wm + ((item >> 2) & (NT_WM - 1)) * 4;
+    const int4 v = *reinterpret_cast<const int4 *>(e);
+    const int tag = __builtin_amdgcn_readfirstlane(v.x);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane(v.y);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane(v.z);
+    const unsigned long long seen = tag == item ? (((unsigned long long)hi << 32) | lo) : 0ull;
+    const bool doit = active && ((seen >> lane) & 1ull) == 0ull;
+    const unsigned long long add = __builtin_amdgcn_ballot_w64(doit);
+    if (add != 0ull && lane == 0) {
+        const unsigned long long now = seen | add;
+        *reinterpret_cast<int4 *>(e) = make_int4(item, (int)(unsigned int)(now & 0xffffffffull), (int)(unsigned int)(now >> 32), 0);
+    }
+    return doit;
+}
+
 // A 256-thread block is four independent waves (no barrier) rendering a 2x2 quad of 8x8 tiles of one frame:
 // neighbouring rays walk the same leaves, so the four waves share what their scalar loads bring into the CU's
 // scalar cache (blocks of unrelated tiles ran ~12 % slower).  Quads are dispatched through a host table: quad
@@ -2280,7 +2340,8 @@ __global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtComposit
     w.ray = lds_wave;                                                      // [N][64] float2 (FEAT only)
     w.stack = reinterpret_cast<int *>(lds_wave + (FEAT ? 64 * N : 0));    // [stack_depth][64] (FEAT only)
     w.mbox = w.stack + (FEAT ? 64 * sc.stack_depth : 0);
-    int *ustack = w.mbox + 64 * NT_MBOX;          // [DEPTH][8]: far node, far-lane mask lo, hi, split, axis
+    int *wm = w.mbox + (FEAT ? 64 * NT_MBOX : 0); // [NT_WM][4] wave mailbox (w.mbox itself: FEAT's per-lane walks)
+    int *ustack = wm + NT_WM * 4;                 // [DEPTH][8]: far node, far-lane mask lo, hi, split, axis
 
     // ---- this wave's tile
     const int quad = pa.order ? pa.order[rank] : rank;
@@ -2317,7 +2378,7 @@ __global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtComposit
     float t_near = dist0, t_far = FLT_MAX;
     int dirty = 0;
     unsigned int bothbits = 0u;   // bit k: this lane entered BOTH sides of the branch pushed at stack level k
-    mbox_reset(w, lane);
+    wm_reset(wm, lane);
 
     int node = sc.root;      // wave-uniform
     int sp = 0;              // wave-uniform
@@ -2333,8 +2394,7 @@ __global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtComposit
                 // records, and its mailbox lookup (LDS) is issued before item i's edge tests, so neither
                 // round trip sits on the critical path
                 int item = __builtin_amdgcn_readfirstlane(sc.items[nd.left]);
-                bool doit = false;
-                if (active) doit = !mbox_seen(w, lane, item);
+                bool doit = wm_claim(wm, lane, item, active);
                 for (int i = 0; i < nd.right; ++i) {
                     const int cur = item;
                     const bool cur_doit = doit;
@@ -2342,7 +2402,7 @@ __global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtComposit
                     if (more) item = __builtin_amdgcn_readfirstlane(sc.items[nd.left + i + 1]);
                     if (__builtin_amdgcn_ballot_w64(cur_doit) == 0ull) {
                         doit = false;
-                        if (more && active) doit = !mbox_seen(w, lane, item);
+                        if (more) doit = wm_claim(wm, lane, item, active);
                         continue;
                     }
                     const float *base = sc.batch_recs + (size_t)(cur >> 2) * NT_DEV_BATCH * sc.rec_stride;
@@ -2363,7 +2423,7 @@ __global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtComposit
                         ok1[l] = denom != 0.0f && tl[l] >= 0.0f;
                     }
                     doit = false;
-                    if (more && active) doit = !mbox_seen(w, lane, item);
+                    if (more) doit = wm_claim(wm, lane, item, active);
                     float min_t = hit.dist;
                     int r = -1;
 #pragma unroll
@@ -2582,10 +2642,10 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
 #define NT_PACKET_CASE(D)                                                                                   \
     if (sc.stack_depth <= D) {                                                                              \
         if (feat) {                                                                                         \
-            pk.lds_per_wave = (int)((size_t)64 * ((size_t)N * 8 + (size_t)sc.stack_depth * 4 + NT_MBOX * 4) + (size_t)D * 32); \
+            pk.lds_per_wave = (int)((size_t)64 * ((size_t)N * 8 + (size_t)sc.stack_depth * 4 + NT_MBOX * 4) + NT_WM * 16 + (size_t)D * 32); \
             hipLaunchKernelGGL((composite_packet<N, D, true>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, tg, pk); \
         } else {                                                                                            \
-            pk.lds_per_wave = (int)((size_t)64 * NT_MBOX * 4 + (size_t)D * 32);                             \
+            pk.lds_per_wave = (int)((size_t)NT_WM * 16 + (size_t)D * 32);                                   \
             hipLaunchKernelGGL((composite_packet<N, D, false>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, tg, pk); \
         }                                                                                                   \
         return 0;                                                                                           \

@@ -8,7 +8,7 @@ g = np.load(os.path.join(ROOT,"tests","golden","cell120_n4.npz"))
 sc = tracern.CompositeScene.from_flat(4, g)
 sc.add_light(tracern.PointLight(tracern.Vector(4, (8.0, 9.0, -7.0, 3.0)), (60.0, 60.0, 60.0)))
 sc.add_light(tracern.GlobalLight(tracern.Vector(4, (0.2, -1.0, 0.3, 0.1)).unit(), (0.5, 0.5, 0.5)))
-sc.set_shadows(True)
+sc.set_shadows(os.environ.get("SHADOWS", "1") != "0")
 W,H=960,540
 fmt = ntracer_amd.ImageFormat(W,H,[ntracer_amd.Channel(8,1,0,0),ntracer_amd.Channel(8,0,1,0),ntracer_amd.Channel(8,0,0,1),ntracer_amd.Channel(8,0,0,0)])
 fst=fmt._as_struct()
