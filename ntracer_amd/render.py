@@ -2,8 +2,12 @@
 
 Same names, argument meaning and error behaviour as the reference's C++ module
 (src/render.cpp), but every render goes through libntracer_hip.so to hand-written
-HIP kernels -- see include/ntracer_hip.h.  Types outside the path (pickling,
-capsules) are intentionally absent.
+HIP kernels -- see include/ntracer_hip.h.  The inter-module capsules of the reference are
+intentionally absent (there is one module per type here, not one per dimension).
+
+Pickling follows the reference's wire format (render.cpp:1094-1099, 1197-1208, 1482-1660, 1696-1751):
+``__reduce__`` returns ``(render._X_unpickle, (dimension, big-endian IEEE-754 floats, ...))``; with
+``ntracer_amd.compat.alias_reference_modules()`` pickles written by the reference load here and vice versa.
 """
 import ctypes as C
 import os
@@ -121,6 +125,9 @@ class Color(object):
     def __iter__(self):
         return iter((self.r, self.g, self.b))
 
+    def __reduce__(self):
+        return _color_unpickle, (_encode_floats((self.r, self.g, self.b)),)
+
     def __len__(self):
         return 3
 
@@ -197,6 +204,10 @@ class Material(object):
         return (tuple(self.color), tuple(self.specular), self.opacity, self.reflectivity, self.specular_intensity,
                 self.specular_exp)
 
+    def __reduce__(self):
+        return _material_unpickle, (_encode_floats(tuple(self.color) + tuple(self.specular) + (
+            self.opacity, self.reflectivity, self.specular_intensity, self.specular_exp)),)
+
     def _as_struct(self):
         m = _lib.NtMaterial()
         m.color[:] = tuple(self.color)
@@ -210,6 +221,102 @@ class Material(object):
     def __repr__(self):
         return "Material(%r,%r,%r,%r,%r,%r)" % (tuple(self.color), self.opacity, self.reflectivity,
                                                 self.specular_intensity, self.specular_exp, tuple(self.specular))
+
+
+# ---- pickling: render.cpp:1400-1660.  Floats travel as big-endian IEEE-754 (encode_float_ieee754, :1400-1437).
+
+def _encode_floats(values):
+    import numpy as np
+    return np.asarray(values, ">f4").tobytes()
+
+
+def _decode_floats(data, count, what):
+    import numpy as np
+    if not isinstance(data, (bytes, bytearray)):
+        raise TypeError("object is not an instance of bytes")
+    if len(data) != 4 * count:
+        raise ValueError("%s data is malformed" % what)
+    return np.frombuffer(bytes(data), ">f4").astype(np.float32)
+
+
+def _dimension(d):
+    d = int(d)
+    if d < 3:
+        raise ValueError("dimension cannot be less than 3")      # get_dimension, render.cpp:1385-1389
+    return d
+
+
+def _color_unpickle(data):
+    v = _decode_floats(data, 3, "color")
+    return Color(float(v[0]), float(v[1]), float(v[2]))
+
+
+def _material_unpickle(data):
+    v = [float(x) for x in _decode_floats(data, 10, "material")]
+    m = Material.__new__(Material)         # the reference assigns the fields without range checks (:1502-1512)
+    m.color = Color(*v[0:3])
+    m.specular = Color(*v[3:6])
+    m.opacity, m.reflectivity, m.specular_intensity, m.specular_exp = v[6:10]
+    return m
+
+
+def _vector_unpickle(dim, data):
+    from . import tracern
+    n = _dimension(dim)
+    return tracern.Vector._wrap(_decode_floats(data, n, "vector"))
+
+
+def _matrix_unpickle(dim, data):
+    from . import tracern
+    n = _dimension(dim)
+    return tracern.Matrix._wrap(_decode_floats(data, n * n, "matrix").reshape(n, n))
+
+
+def _triangle_unpickle(dim, data, material):
+    from . import tracern
+    n = _dimension(dim)
+    v = _decode_floats(data, n * (n + 1), "triangle").reshape(n + 1, n)      # p1, face_normal, edge normals
+    if not isinstance(material, Material):
+        raise TypeError("object is not an instance of Material")
+    return tracern.Triangle(v[0], v[1], v[2:], material)
+
+
+def _triangle_batch_unpickle(batch_size, dim, data, *materials):
+    from . import tracern
+    n = _dimension(dim)
+    if int(batch_size) != tracern.BATCH_SIZE:
+        raise TypeError("The TriangleBatch instance was pickled with a different batch size. It cannot be loaded here.")
+    if len(materials) != tracern.BATCH_SIZE:
+        raise TypeError("wrong number of arguments")
+    # rows p1, face_normal, edge normals; each row [component][lane] (vector<Store,v_real>, tracer.hpp:532-548)
+    v = _decode_floats(data, tracern.BATCH_SIZE * n * (n + 1), "triangle batch").reshape(n + 1, n, tracern.BATCH_SIZE)
+    for m in materials:
+        if not isinstance(m, Material):
+            raise TypeError("object is not an instance of Material")
+    return tracern.TriangleBatch([tracern.Triangle(v[0, :, l], v[1, :, l], v[2:, :, l], materials[l])
+                                  for l in range(tracern.BATCH_SIZE)])
+
+
+def _solid_unpickle(dim, data, material):
+    from . import tracern
+    n = _dimension(dim)
+    if not isinstance(data, (bytes, bytearray)):
+        raise TypeError("object is not an instance of bytes")
+    if len(data) != 4 * n * (n + 1) + 1:
+        raise ValueError("solid data is malformed")
+    if data[0] not in (1, 2):
+        raise ValueError("solid data is corrupt")
+    if not isinstance(material, Material):
+        raise TypeError("object is not an instance of Material")
+    v = _decode_floats(bytes(data[1:]), n * (n + 1), "solid")
+    return tracern.Solid(int(data[0]), v[n * n:], tracern.Matrix._wrap(v[:n * n].reshape(n, n)), material)
+
+
+def _aabb_unpickle(dim, data):
+    from . import tracern
+    n = _dimension(dim)
+    v = _decode_floats(data, 2 * n, "AABB")
+    return tracern.AABB(n, v[:n], v[n:])
 
 
 class Scene(object):

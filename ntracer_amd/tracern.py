@@ -12,6 +12,7 @@ import math
 import numpy as np
 
 from . import _lib, builder
+from . import render as _render
 from .render import Color, Material, Scene
 
 BATCH_SIZE = _lib.NT_BATCH_SIZE     # tracer.hpp:34-38 (SSE reference build)
@@ -54,6 +55,9 @@ class Vector(object):
         return Vector._wrap(v)
 
     dimension = property(lambda s: len(s._v))
+
+    def __reduce__(self):                               # obj_Vector_reduce, render.cpp:1705-1710
+        return _render._vector_unpickle, (len(self._v), _render._encode_floats(self._v))
 
     def __len__(self):
         return len(self._v)
@@ -138,6 +142,9 @@ class Matrix(object):
         return m
 
     dimension = property(lambda s: s._m.shape[0])
+
+    def __reduce__(self):                               # obj_Matrix_reduce, render.cpp:1711-1715
+        return _render._matrix_unpickle, (self._m.shape[0], _render._encode_floats(self._m.ravel()))
 
     @staticmethod
     def identity(dimension):
@@ -302,6 +309,9 @@ class AABB(object):
         self.start = Vector(n, start) if start is not None else Vector._wrap(np.full(n, np.finfo(f32).min, f32))
         self.end = Vector(n, end) if end is not None else Vector._wrap(np.full(n, np.finfo(f32).max, f32))
 
+    def __reduce__(self):                               # obj_AABB_reduce, render.cpp:1745-1752
+        return _render._aabb_unpickle, (self.dimension, _render._encode_floats(np.concatenate([self.start._v, self.end._v])))
+
 
 class PointLight(object):
     """tracern.PointLight(position,color) -- tracer.hpp:1678-1689."""
@@ -364,6 +374,12 @@ class Triangle(Primitive):
         pts = builder.to_points_array(self.p1._v, self.face_normal._v, [e._v for e in self.edge_normals])
         return tuple(Vector._wrap(p) for p in pts)
 
+    def _rows(self):
+        return np.vstack([self.p1._v, self.face_normal._v] + [e._v for e in self.edge_normals])      # [n+1][n]
+
+    def __reduce__(self):                               # obj_Triangle_reduce, ntracer_body.hpp:1217-1233
+        return _render._triangle_unpickle, (self.dimension, _render._encode_floats(self._rows().ravel()), self.material)
+
     def _record(self):
         rec = [f32(self.d)] + list(self.face_normal._v) + list(self.p1._v)
         for e in self.edge_normals:
@@ -390,6 +406,11 @@ class TriangleBatch(PrimitiveBatch):
     def __getitem__(self, i):
         return self._tris[i]
 
+    def __reduce__(self):                               # rows [component][lane], render.cpp:1725-1735
+        vals = np.stack([t._rows() for t in self._tris], axis=2)          # [n+1][n][BATCH_SIZE]
+        return _render._triangle_batch_unpickle, (BATCH_SIZE, self.dimension, _render._encode_floats(vals.ravel())) + tuple(
+            t.material for t in self._tris)
+
 
 class Solid(Primitive):
     """tracern.Solid(type,position,orientation,material) -- tracer.hpp:231-289."""
@@ -409,6 +430,10 @@ class Solid(Primitive):
         self.material = material
 
     dimension = property(lambda s: s.orientation.dimension)
+
+    def __reduce__(self):                               # obj_Solid_reduce, render.cpp:1736-1744
+        data = bytes([self.type]) + _render._encode_floats(self.orientation._m.ravel()) + _render._encode_floats(self.position._v)
+        return _render._solid_unpickle, (self.dimension, data, self.material)
 
 
 class KDNode(object):

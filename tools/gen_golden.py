@@ -482,6 +482,50 @@ def gen_from_points():
     print("wrote from_points")
 
 
+def gen_pickles():
+    """Pickles of the reference's picklable types (render.cpp:1094-1099,1197-1208,1696-1751; __reduce__ of
+    Vector, Matrix, Triangle, TriangleBatch, Solid, AABB in ntracer_body.hpp): the pickle byte strings
+    (protocol 2) and the values they were made from.  Data only."""
+    import pickle
+    import random
+    rnd = random.Random(7)
+    out = {}
+    names = []
+
+    def put(name, obj, values):
+        out["pickle_" + name] = np.frombuffer(pickle.dumps(obj, 2), np.uint8)
+        out["values_" + name] = np.asarray(values, np.float32)
+        names.append(name)
+
+    put("color", R.Color(0.25, 0.5, 0.75), [0.25, 0.5, 0.75])
+    m = Material((1.0, 0.5, 0.25), 0.75, 0.125, 0.5, 12.0, (0.5, 0.25, 1.0))
+    put("material", m, [1.0, 0.5, 0.25, 0.5, 0.25, 1.0, 0.75, 0.125, 0.5, 12.0])
+    for n in (3, 5, 9):
+        nt = NTracer(n)
+        v = [rnd.uniform(-2, 2) for _ in range(n)]
+        put("vector%d" % n, nt.Vector(*v), v)
+        mv = [[rnd.uniform(-2, 2) for _ in range(n)] for _ in range(n)]
+        put("matrix%d" % n, nt.Matrix(mv), mv)
+        put("aabb%d" % n, nt.AABB(nt.Vector(*[-1.0 - i for i in range(n)]), nt.Vector(*[2.0 + i for i in range(n)])),
+            [[-1.0 - i for i in range(n)], [2.0 + i for i in range(n)]])
+        pts = [[rnd.uniform(-3, 3) for _ in range(n)] for _ in range(n)]
+        t = nt.Triangle.from_points([nt.Vector(*q) for q in pts], m)
+        rec = [list(t.p1), list(t.face_normal)] + [list(e) for e in t.edge_normals]
+        put("triangle%d" % n, t, rec)
+        tris = []
+        for k in range(4):
+            q = [[rnd.uniform(-3, 3) for _ in range(n)] for _ in range(n)]
+            tris.append(nt.Triangle.from_points([nt.Vector(*x) for x in q], m))
+        tb = nt.TriangleBatch(tris)
+        put("batch%d" % n, tb, [[list(x.p1), list(x.face_normal)] + [list(e) for e in x.edge_normals] for x in tris])
+        rot = nt.Matrix.rotation(nt.Vector.axis(0), nt.Vector.axis(1), 0.3) * nt.Matrix.scale(1.5)
+        so = nt.Solid(W.CUBE if n != 5 else W.SPHERE, nt.Vector(*[0.5 * i for i in range(n)]), rot, m)
+        put("solid%d" % n, so, list(so.orientation.values) + list(so.position))
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "pickles.npz"), **out)
+    print("wrote pickles", names)
+
+
 def gen_kdtree_known_answer():
     """Per-stage capture on the 600-cell: nearest-hit records through
     KDNode.intersects for a fan of rays (advisory, cross-checked in tests
@@ -501,6 +545,7 @@ if __name__ == "__main__":
         "cell120": lambda: gen_polytope("cell120_n4", ["5/2", "3", "3"], 1920, 1080, [0, 11, 52, 97, 140], (37, 29)),
         "feature": gen_feature_scene,
         "from_points": gen_from_points,
+        "pickles": gen_pickles,
         # a 10-D simplex {3,3,3,3,3,3,3,3,3}: composite scene through the generic (var_geometry) module
         "simplex10": lambda: gen_polytope("simplex10_n10", ["3"] * 9, 320, 200, [0, 9, 47, 120], (5, 3)),
         # a 5-D cross-polytope-like {3,3,3,4}: 32 facets, fixed<5> module
