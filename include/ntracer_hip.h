@@ -216,6 +216,30 @@ int nt_colors_at(nt_scene_t *s, int width, int height, int count, const int32_t 
 /* statistics of the last render on this scene that had collect_stats set */
 int nt_scene_last_stats(const nt_scene_t *s, nt_stats *out);
 
+/* ---- scene construction (host only, no device needed) --------------------------------------------------
+   build_kdtree / build_composite_scene of the reference (src/tracer.hpp:1965-2455; Python entry points
+   src/ntracer_body.hpp:3250-3357).  Items are primitives or batches: a bounding box each, plus -- for
+   simplices -- their vertices, simplex_first[i] .. simplex_first[i+1] indexing simplex_verts [count][n][n]
+   (an item without simplices, e.g. a Solid, is placed by its box).  The tree comes back in the flat layout of
+   nt_scene_desc (leaf: axis -1, left = first entry of leaf_items, right = count); leaf_items holds ITEM
+   indices.  Arrays are malloc'ed; release with nt_kdtree_free.  max_depth / split_threshold <= 0 select the
+   reference's defaults (25, 2; tracer.hpp:41-44). */
+typedef struct {
+    int32_t root;
+    int32_t n_nodes;
+    int32_t n_leaf_items;
+    int32_t *node_axis;
+    float *node_split;
+    int32_t *node_left;
+    int32_t *node_right;
+    int32_t *leaf_items;
+    float *aabb;                 /* start[n], end[n] */
+} nt_kdtree;
+
+int nt_kdtree_build(int dimension, int n_items, const float *item_lo, const float *item_hi, const int32_t *simplex_first,
+                    const float *simplex_verts, int max_depth, int split_threshold, nt_kdtree *out);
+void nt_kdtree_free(nt_kdtree *t);
+
 #ifdef __cplusplus
 }
 #endif

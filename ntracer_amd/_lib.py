@@ -78,6 +78,12 @@ class NtStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class NtKdTree(C.Structure):
+    _fields_ = [("root", C.c_int32), ("n_nodes", C.c_int32), ("n_leaf_items", C.c_int32),
+                ("node_axis", i32p), ("node_split", f32p), ("node_left", i32p), ("node_right", i32p),
+                ("leaf_items", i32p), ("aabb", f32p)]
+
+
 # every symbol include/ntracer_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("nt_version", C.c_char_p, []),
@@ -106,6 +112,8 @@ SYMBOLS = [
     ("nt_calculate_color", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
     ("nt_colors_at", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, i32p, f32p, C.c_int]),
     ("nt_scene_last_stats", C.c_int, [C.c_void_p, C.POINTER(NtStats)]),
+    ("nt_kdtree_build", C.c_int, [C.c_int, C.c_int, f32p, f32p, i32p, f32p, C.c_int, C.c_int, C.POINTER(NtKdTree)]),
+    ("nt_kdtree_free", None, [C.POINTER(NtKdTree)]),
 ]
 
 _lib = None

@@ -5,9 +5,13 @@
 
 Host-side, runs once per scene.  The plane / edge-normal records are computed in float64 and rounded to fp32
 (the reference runs an fp32 LU; values agree to ~1e-7 relative).  The k-d builder is NOT a restatement of the
-reference's: nearest-hit results do not depend on the tree, so this one is a plain SAH sweep
-over primitive bounding boxes with conservative (bounding-box) overlap -- a primitive may land in a cell it only
-touches, which costs a test but never a hit.  The reference's cost constants and limits are kept
+reference's: nearest-hit results do not depend on the tree.  It is a SAH sweep whose split
+candidates come from each simplex's EDGES clipped to the cell (so a long thin simplex crossing a cell diagonally
+counts where it actually is, not over its whole bounding box), and whose membership test is a set of separating
+axes -- bounding box, the simplex's hyperplane against the cell, and the simplex's shadow against the cell's in
+every coordinate plane.  Every axis test is a proof of disjointness, so a primitive may land in a cell it only
+nearly touches (costs a test) but is never left out of one it enters (would cost a hit; the kernels' early exit
+and pruning rely on this, like the reference's own walk).  The reference's cost constants and limits are kept
 (KD_DEFAULT_MAX_DEPTH = 25, split threshold 2; tracer.hpp:41-44).
 """
 import numpy as np
@@ -97,12 +101,15 @@ def solid_bounds(type_cube, position, orientation):
 
 
 class _Item(object):
-    __slots__ = ("prim", "lo", "hi")
+    """A primitive (or batch) for the builder: its bounding box and, for simplices, the vertex arrays
+    (count, n, n); None for solids, which are placed by bounding box alone."""
+    __slots__ = ("prim", "lo", "hi", "simplices")
 
-    def __init__(self, prim, lo, hi):
+    def __init__(self, prim, lo, hi, simplices=None):
         self.prim = prim
         self.lo = np.asarray(lo, np.float64)
         self.hi = np.asarray(hi, np.float64)
+        self.simplices = None if simplices is None else np.asarray(simplices, np.float64).reshape(-1, len(self.lo), len(self.lo))
 
 
 def group_batches(tri_items, batch_size, make_batch):
@@ -136,87 +143,64 @@ def group_batches(tri_items, batch_size, make_batch):
             members = [tri_items[i] for i in grp]
             lo = np.min([g.lo for g in members], axis=0)
             hi = np.max([g.hi for g in members], axis=0)
-            batches.append(_Item(make_batch([g.prim for g in members]), lo, hi))
+            simp = None
+            if all(g.simplices is not None for g in members):
+                simp = np.concatenate([g.simplices for g in members])
+            batches.append(_Item(make_batch([g.prim for g in members]), lo, hi, simp))
         else:
             loose.extend(tri_items[i] for i in grp)
     return batches, loose
 
 
 def build_tree(items, make_leaf, make_branch, max_depth=KD_DEFAULT_MAX_DEPTH, split_threshold=KD_DEFAULT_SPLIT_THRESHOLD):
-    """SAH k-d tree over item bounding boxes.  Returns (lo, hi, root)."""
+    """SAH k-d tree over the items, built by the native builder (csrc/nt_builder.cpp, nt_kdtree_build): exact
+    clipping of every simplex to every cell it is tested against.  Returns (lo, hi, root) with the nodes made
+    through make_leaf(list of prims) / make_branch(axis, split, left, right)."""
+    import ctypes as C
+    from . import _lib
     if not items:
         raise ValueError("cannot build a k-d tree from zero primitives")
-    los = np.asarray([it.lo for it in items])
-    his = np.asarray([it.hi for it in items])
-    lo = los.min(axis=0)
-    hi = his.max(axis=0)
-    n = len(lo)
-
-    def area(l, h):
-        # surface measure of an n-box up to a constant: sum over axes of the product of the other extents
-        e = np.maximum(h - l, 0.0)
-        if n == 1:
-            return 1.0
-        tot = 0.0
-        for a in range(n):
-            tot += float(np.prod(np.delete(e, a)))
-        return tot
-
-    def rec(idx, l, h, depth):
-        if len(idx) <= split_threshold or depth >= max_depth:
-            return make_leaf([items[i].prim for i in idx])
-        base = area(l, h)
-        best = None
-        leaf_cost = INTERSECTION_COST * len(idx)
-        if base > 0.0:
-            for axis in np.argsort(-(h - l))[:min(n, 3)]:
-                axis = int(axis)
-                if h[axis] - l[axis] <= 0.0:
-                    continue
-                s = los[idx, axis]
-                e = his[idx, axis]
-                cands = np.unique(np.concatenate([s, e]))
-                cands = cands[(cands > l[axis]) & (cands < h[axis])]
-                if len(cands) == 0:
-                    continue
-                if len(cands) > 256:
-                    cands = cands[np.linspace(0, len(cands) - 1, 256).astype(int)]
-                flat = ((s[None, :] == cands[:, None]) & (e[None, :] == cands[:, None])).sum(axis=1)
-                nl = (s[None, :] < cands[:, None]).sum(axis=1) + flat
-                nr = (e[None, :] > cands[:, None]).sum(axis=1) + flat
-                # area of a box is linear in its extent along `axis`: A0 + A1*x
-                ext = np.maximum(h - l, 0.0)
-                others = np.delete(ext, axis)
-                a0 = float(np.prod(others))
-                a1 = sum(float(np.prod(np.delete(others, k))) for k in range(len(others))) if len(others) > 1 else 1.0
-                cost = TRAVERSAL_COST + INTERSECTION_COST * ((a0 + a1 * (cands - l[axis])) * nl + (a0 + a1 * (h[axis] - cands)) * nr) / base
-                cost = np.where((nl == 0) | (nr == 0), cost * 0.8, cost)      # cutting off empty space is worth more
-                k = int(np.argmin(cost))
-                if best is None or cost[k] < best[0]:
-                    best = (float(cost[k]), axis, float(cands[k]), int(nl[k]), int(nr[k]))
-        if best is None or best[0] >= leaf_cost or (best[3] == len(idx) and best[4] == len(idx)):
-            return make_leaf([items[i].prim for i in idx])
-        _, axis, c, _, _ = best
-        c32 = float(f32(c))
-        s = los[idx, axis]
-        e = his[idx, axis]
-        # conservative membership with the fp32 split the kernels will see; flat primitives in the plane go both ways
-        left = idx[(s < c32) | ((s <= c32) & (e <= c32) & (s == e))]
-        right = idx[(e > c32) | ((s >= c32) & (e >= c32) & (s == e))]
-        both_flat = idx[(s == c32) & (e == c32)]
-        left = np.union1d(left, both_flat)
-        right = np.union1d(right, both_flat)
-        if len(left) == len(idx) and len(right) == len(idx):
-            return make_leaf([items[i].prim for i in idx])
-        hl = h.copy()
-        hl[axis] = c32
-        lr = l.copy()
-        lr[axis] = c32
-        ln = rec(left, l, hl, depth + 1) if len(left) else None
-        rn = rec(right, lr, h, depth + 1) if len(right) else None
-        if ln is None and rn is None:
-            return make_leaf([items[i].prim for i in idx])
-        return make_branch(axis, c32, ln, rn)
-
-    root = rec(np.arange(len(items)), lo.copy(), hi.copy(), 0)
-    return lo.astype(f32), hi.astype(f32), root
+    n = len(items[0].lo)
+    los = np.ascontiguousarray([it.lo for it in items], f32)
+    his = np.ascontiguousarray([it.hi for it in items], f32)
+    first = np.zeros(len(items) + 1, np.int32)
+    verts = []
+    for k, it in enumerate(items):
+        if it.simplices is not None:
+            verts.append(it.simplices)
+            first[k + 1] = first[k] + len(it.simplices)
+        else:
+            first[k + 1] = first[k]
+    sv = np.ascontiguousarray(np.concatenate(verts) if verts else np.zeros((0, n, n)), f32)
+    out = _lib.NtKdTree()
+    _lib.check(_lib.lib().nt_kdtree_build(n, len(items), los.ctypes.data_as(_lib.f32p), his.ctypes.data_as(_lib.f32p),
+                                          first.ctypes.data_as(_lib.i32p), sv.ctypes.data_as(_lib.f32p),
+                                          int(max_depth), int(split_threshold), C.byref(out)))
+    try:
+        nn = out.n_nodes
+        axis = np.ctypeslib.as_array(out.node_axis, (nn,)).copy()
+        split = np.ctypeslib.as_array(out.node_split, (nn,)).copy()
+        left = np.ctypeslib.as_array(out.node_left, (nn,)).copy()
+        right = np.ctypeslib.as_array(out.node_right, (nn,)).copy()
+        leaf_items = np.ctypeslib.as_array(out.leaf_items, (max(out.n_leaf_items, 1),)).copy()
+        box = np.ctypeslib.as_array(out.aabb, (2 * n,)).copy()
+        root = out.root
+    finally:
+        _lib.lib().nt_kdtree_free(C.byref(out))
+    made = {}
+    # children before parents, without recursion (trees are up to max_depth deep but can be wide)
+    order, stack = [], [root]
+    while stack:
+        k = stack.pop()
+        order.append(k)
+        if axis[k] >= 0:
+            for c in (left[k], right[k]):
+                if c >= 0:
+                    stack.append(c)
+    for k in reversed(order):
+        if axis[k] < 0:
+            made[k] = make_leaf([items[i].prim for i in leaf_items[left[k]:left[k] + right[k]]])
+        else:
+            made[k] = make_branch(int(axis[k]), float(split[k]), made.get(left[k]) if left[k] >= 0 else None,
+                                  made.get(right[k]) if right[k] >= 0 else None)
+    return box[:n].astype(f32), box[n:].astype(f32), made[root]

@@ -893,7 +893,8 @@ def build_kdtree(primitives, extra_threads=-1, **kwds):
     n = protos[0].dimension
     if any(p.dimension != n for p in protos):
         raise TypeError("the primitive prototypes must all have the same dimension")
-    tri = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v) for p in protos if isinstance(p, TrianglePrototype)]
+    tri = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v, [[list(q) for q in p.point_data]]) for p in protos
+           if isinstance(p, TrianglePrototype)]
     other = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v) for p in protos if not isinstance(p, TrianglePrototype)]
     batches, loose = builder.group_batches(tri, BATCH_SIZE, TriangleBatch)
     lo, hi, root = builder.build_tree(batches + loose + other, KDLeaf, KDBranch, max_depth, split_threshold)

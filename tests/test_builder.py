@@ -61,6 +61,54 @@ def test_built_tree_renders_like_the_reference_tree():
         assert cnt["batch_tests"] / cnt["rays"] < 40          # the tree actually prunes (150 batches in the scene)
 
 
+def test_native_builder_beats_the_reference_tree_on_the_600_cell():
+    """Same scene, same batches' worth of geometry: the tree built by nt_kdtree_build (exact clipping) must not cost
+    the oracle more batch tests per ray than the tree the reference built (fixture), and it must be much smaller."""
+    g = fx.load("cell600_n4")
+    recs = g["batch_recs"].reshape(-1, 21)
+    nt = NTracer(4)
+    protos = [nt.TrianglePrototype(builder.vertices_of(r[5:9], r[1:5], r[9:].reshape(3, 4)), MAT) for r in recs]
+    boundary, root = tracern.build_kdtree(protos)
+    flat = _flat_of_scene(boundary, root)
+    f = g["frames"][0]
+    ys, xs = np.mgrid[0:360:6, 0:640:6]
+    _, ours = ob.OracleScene(4, g["origins"][f], g["axes"][f], flat=flat).colors_at(xs.ravel(), ys.ravel(), 640, 360, counters=True)
+    _, ref = ob.OracleScene(4, g["origins"][f], g["axes"][f], flat=fx.flat_of(g)).colors_at(xs.ravel(), ys.ravel(), 640, 360, counters=True)
+    assert ours["batch_tests"] <= 1.1 * ref["batch_tests"]
+    assert ours["branches"] <= ref["branches"]
+    assert len(flat["node_axis"]) < len(g["node_axis"])
+
+
+def test_kdtree_build_abi():
+    import ctypes as C
+    from ntracer_amd import _lib
+    L = _lib.lib()
+    n = 3
+    tris = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[5, 5, 5], [6, 5, 5], [5, 6, 5]], [[0, 0, 4], [1, 0, 4], [0, 1, 4]]], np.float32)
+    lo = np.ascontiguousarray(tris.min(axis=1))
+    hi = np.ascontiguousarray(tris.max(axis=1))
+    first = np.arange(4, dtype=np.int32)
+    out = _lib.NtKdTree()
+    assert L.nt_kdtree_build(n, 3, lo.ctypes.data_as(_lib.f32p), hi.ctypes.data_as(_lib.f32p), first.ctypes.data_as(_lib.i32p),
+                             tris.ctypes.data_as(_lib.f32p), 0, 0, C.byref(out)) == _lib.NT_OK
+    axis = np.ctypeslib.as_array(out.node_axis, (out.n_nodes,)).copy()
+    cnt = np.ctypeslib.as_array(out.node_right, (out.n_nodes,)).copy()
+    items = np.ctypeslib.as_array(out.leaf_items, (out.n_leaf_items,)).copy()
+    box = np.ctypeslib.as_array(out.aabb, (6,)).copy()
+    L.nt_kdtree_free(C.byref(out))
+    assert out.n_nodes == 0 and not out.node_axis                       # freed and zeroed
+    assert sorted(items.tolist()) == [0, 1, 2]                          # three triangles far apart: no duplicates
+    assert (axis >= 0).sum() == 1 and sorted(cnt[axis < 0].tolist()) == [1, 2]      # split threshold 2
+    assert np.allclose(box, [0, 0, 0, 6, 6, 5])
+    # argument checks
+    assert L.nt_kdtree_build(n, 0, lo.ctypes.data_as(_lib.f32p), hi.ctypes.data_as(_lib.f32p), first.ctypes.data_as(_lib.i32p),
+                             tris.ctypes.data_as(_lib.f32p), 0, 0, C.byref(out)) == _lib.NT_E_INVALID
+    assert L.nt_kdtree_build(n, 3, hi.ctypes.data_as(_lib.f32p), lo.ctypes.data_as(_lib.f32p), first.ctypes.data_as(_lib.i32p),
+                             tris.ctypes.data_as(_lib.f32p), 0, 0, C.byref(out)) == _lib.NT_E_INVALID     # lo > hi
+    assert L.nt_kdtree_build(n, 3, lo.ctypes.data_as(_lib.f32p), hi.ctypes.data_as(_lib.f32p), first.ctypes.data_as(_lib.i32p),
+                             tris.ctypes.data_as(_lib.f32p), 0, 0, None) == _lib.NT_E_INVALID
+
+
 def test_tree_independence_with_solids_and_loose_triangles():
     """A mixed 3-D scene (solids, 6 loose triangles + batches): the built tree must give the same colours as a
     single leaf holding everything (brute force)."""
