@@ -222,8 +222,7 @@ int nt_scene_last_stats(const nt_scene_t *s, nt_stats *out);
    simplices -- their vertices, simplex_first[i] .. simplex_first[i+1] indexing simplex_verts [count][n][n]
    (an item without simplices, e.g. a Solid, is placed by its box).  The tree comes back in the flat layout of
    nt_scene_desc (leaf: axis -1, left = first entry of leaf_items, right = count); leaf_items holds ITEM
-   indices.  Arrays are malloc'ed; release with nt_kdtree_free.  max_depth / split_threshold <= 0 select the
-   reference's defaults (25, 2; tracer.hpp:41-44). */
+   indices.  Arrays are malloc'ed; release with nt_kdtree_free. */
 typedef struct {
     int32_t root;
     int32_t n_nodes;
@@ -236,8 +235,18 @@ typedef struct {
     float *aabb;                 /* start[n], end[n] */
 } nt_kdtree;
 
+/* kd_tree_params (tracer.hpp:1948-1961).  Zero / negative fields select the defaults: depth 25, threshold 2,
+   costs 1 : 1 (the reference's per-dimension constants, :1933-1946, were tuned for its CPU walk; on the GPU a
+   branch step is cheap next to a 4-simplex batch test). */
+typedef struct {
+    int32_t max_depth;           /* <= 64 */
+    int32_t split_threshold;
+    float traversal_cost;
+    float intersection_cost;
+} nt_kdtree_params;
+
 int nt_kdtree_build(int dimension, int n_items, const float *item_lo, const float *item_hi, const int32_t *simplex_first,
-                    const float *simplex_verts, int max_depth, int split_threshold, nt_kdtree *out);
+                    const float *simplex_verts, const nt_kdtree_params *params, nt_kdtree *out);
 void nt_kdtree_free(nt_kdtree *t);
 
 #ifdef __cplusplus

@@ -78,6 +78,11 @@ class NtStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class NtKdTreeParams(C.Structure):
+    _fields_ = [("max_depth", C.c_int32), ("split_threshold", C.c_int32), ("traversal_cost", C.c_float),
+                ("intersection_cost", C.c_float)]
+
+
 class NtKdTree(C.Structure):
     _fields_ = [("root", C.c_int32), ("n_nodes", C.c_int32), ("n_leaf_items", C.c_int32),
                 ("node_axis", i32p), ("node_split", f32p), ("node_left", i32p), ("node_right", i32p),
@@ -112,7 +117,7 @@ SYMBOLS = [
     ("nt_calculate_color", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
     ("nt_colors_at", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, i32p, f32p, C.c_int]),
     ("nt_scene_last_stats", C.c_int, [C.c_void_p, C.POINTER(NtStats)]),
-    ("nt_kdtree_build", C.c_int, [C.c_int, C.c_int, f32p, f32p, i32p, f32p, C.c_int, C.c_int, C.POINTER(NtKdTree)]),
+    ("nt_kdtree_build", C.c_int, [C.c_int, C.c_int, f32p, f32p, i32p, f32p, C.POINTER(NtKdTreeParams), C.POINTER(NtKdTree)]),
     ("nt_kdtree_free", None, [C.POINTER(NtKdTree)]),
 ]
 

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "nt_api.cpp"), os.path.join(HERE, "csrc", "nt_builder.cpp"), os.path.join(HERE, "csrc", "nt_kernels.hip")]
 HDR = [os.path.join(HERE, "csrc", "nt_device.hpp"), os.path.join(HERE, "..", "include", "ntracer_hip.h")]
 OUT = os.path.join(HERE, "libntracer_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wall",
          "-Wno-unused-function"]
 
 

@@ -152,7 +152,8 @@ def group_batches(tri_items, batch_size, make_batch):
     return batches, loose
 
 
-def build_tree(items, make_leaf, make_branch, max_depth=KD_DEFAULT_MAX_DEPTH, split_threshold=KD_DEFAULT_SPLIT_THRESHOLD):
+def build_tree(items, make_leaf, make_branch, max_depth=KD_DEFAULT_MAX_DEPTH, split_threshold=KD_DEFAULT_SPLIT_THRESHOLD,
+               traversal_cost=0.0, intersection_cost=0.0):
     """SAH k-d tree over the items, built by the native builder (csrc/nt_builder.cpp, nt_kdtree_build): exact
     clipping of every simplex to every cell it is tested against.  Returns (lo, hi, root) with the nodes made
     through make_leaf(list of prims) / make_branch(axis, split, left, right)."""
@@ -173,9 +174,10 @@ def build_tree(items, make_leaf, make_branch, max_depth=KD_DEFAULT_MAX_DEPTH, sp
             first[k + 1] = first[k]
     sv = np.ascontiguousarray(np.concatenate(verts) if verts else np.zeros((0, n, n)), f32)
     out = _lib.NtKdTree()
+    params = _lib.NtKdTreeParams(int(max_depth), int(split_threshold), float(traversal_cost), float(intersection_cost))
     _lib.check(_lib.lib().nt_kdtree_build(n, len(items), los.ctypes.data_as(_lib.f32p), his.ctypes.data_as(_lib.f32p),
                                           first.ctypes.data_as(_lib.i32p), sv.ctypes.data_as(_lib.f32p),
-                                          int(max_depth), int(split_threshold), C.byref(out)))
+                                          C.byref(params), C.byref(out)))
     try:
         nn = out.n_nodes
         axis = np.ctypeslib.as_array(out.node_axis, (nn,)).copy()

@@ -16,11 +16,14 @@
 // box cut to the cell.  Nearest-hit results do not depend on the tree, so none of this is part of the parity
 // contract; the kernels' early exit needs only that no primitive is missing from a cell it enters.
 #include <algorithm>
+#include <atomic>
+#include <system_error>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../include/ntracer_hip.h"
@@ -29,18 +32,60 @@ namespace {
 
 constexpr int NT_CLIP_MAX_VERTS = 4096;
 constexpr int KD_MAX_DIM = 64;
-constexpr double TRAVERSAL_COST = 1.0;
-constexpr double INTERSECTION_COST = 1.0;
-
-struct ClipVert {
-    std::vector<double> x;      // position, n coordinates
-    uint64_t tight[3];          // constraints tight at this vertex: bits 0..n-1 = barycentric facets, then 2 per axis
-};
+constexpr int KD_CLIP_DIM = 16;        // exact clipping up to this dimension; beyond it items are placed by bounding box
 
 inline int popcount3(const uint64_t *a, const uint64_t *b) {
     return __builtin_popcountll(a[0] & b[0]) + __builtin_popcountll(a[1] & b[1]) + __builtin_popcountll(a[2] & b[2]);
 }
 inline void setbit(uint64_t *m, int b) { m[b >> 6] |= 1ull << (b & 63); }
+
+struct Out {                    // a (sub)tree in the flat layout
+    std::vector<int32_t> node_axis, node_left, node_right, leaf_items;
+    std::vector<float> node_split;
+    // append `src` (a complete subtree); returns the new index of its node `root`
+    int append(const Out &src, int root) {
+        const int nb = (int)node_axis.size(), ib = (int)leaf_items.size();
+        for (size_t k = 0; k < src.node_axis.size(); ++k) {
+            const bool leaf = src.node_axis[k] < 0;
+            node_axis.push_back(src.node_axis[k]);
+            node_split.push_back(src.node_split[k]);
+            node_left.push_back(leaf ? src.node_left[k] + ib : (src.node_left[k] >= 0 ? src.node_left[k] + nb : -1));
+            node_right.push_back(leaf ? src.node_right[k] : (src.node_right[k] >= 0 ? src.node_right[k] + nb : -1));
+        }
+        leaf_items.insert(leaf_items.end(), src.leaf_items.begin(), src.leaf_items.end());
+        return root + nb;
+    }
+};
+
+// The references of one cell: item ids, each item's extent inside the cell, and -- for simplices -- what is left
+// of each simplex inside the cell, as a vertex list (positions + the constraints tight at each vertex).  A child
+// cell is the parent cut by ONE more plane, so the polytopes are cut incrementally on the way down.
+struct Refs {
+    int n = 0;
+    std::vector<int> item;
+    std::vector<double> cmin, cmax;          // [ref][n]
+    std::vector<unsigned char> boxed;        // 1: placed by bounding box (solid, clip overflow, n > KD_CLIP_DIM)
+    std::vector<int> slot_first;             // [ref+1]: first polytope slot of the ref (one slot per simplex)
+    std::vector<int> vert_first;             // [slot+1]: first vertex of the polytope (empty polytope: no vertices)
+    std::vector<double> vx;                  // [vertex][n]
+    std::vector<uint64_t> vt;                // [vertex][3]
+
+    int size() const { return (int)item.size(); }
+    void begin(int dim) { n = dim; slot_first.assign(1, 0); vert_first.assign(1, 0); }
+    void release() { *this = Refs(); }
+    // append all of `o` (same n)
+    void append(const Refs &o) {
+        const int sb = vert_first.empty() ? 0 : (int)vert_first.size() - 1, vb = (int)(vx.size() / std::max(n, 1));
+        item.insert(item.end(), o.item.begin(), o.item.end());
+        cmin.insert(cmin.end(), o.cmin.begin(), o.cmin.end());
+        cmax.insert(cmax.end(), o.cmax.begin(), o.cmax.end());
+        boxed.insert(boxed.end(), o.boxed.begin(), o.boxed.end());
+        for (size_t k = 1; k < o.slot_first.size(); ++k) slot_first.push_back(o.slot_first[k] + sb);
+        for (size_t k = 1; k < o.vert_first.size(); ++k) vert_first.push_back(o.vert_first[k] + vb);
+        vx.insert(vx.end(), o.vx.begin(), o.vx.end());
+        vt.insert(vt.end(), o.vt.begin(), o.vt.end());
+    }
+};
 
 struct Builder {
     int n;
@@ -49,94 +94,146 @@ struct Builder {
     const int32_t *simplex_first;
     const float *simplex_verts;
     int max_depth, split_threshold;
+    double TRAVERSAL_COST, INTERSECTION_COST;
     double scale;
+    int threads = 1;
 
-    std::vector<int32_t> node_axis, node_left, node_right, leaf_items;
-    std::vector<float> node_split;
+    Out top;
+    std::atomic<int> spare_threads{0};
 
-    // exact extent of simplex s inside [lo,hi]; false when nothing (of positive measure along some axis) is left
-    bool clip_simplex(int s, const double *lo, const double *hi, double *cmin, double *cmax, bool &overflow) const {
+    // Cut the polytope (nv vertices at x/t) with the half-space sgn*(x_a - bound) >= 0, append what is left to `dst`
+    // as a new slot.  Returns false if the result outgrew NT_CLIP_MAX_VERTS (nothing appended).
+    bool cut(const double *x, const uint64_t *t, int nv, int a, double sgn, double bound, int cbit, Refs &dst) const {
         const double eps = 1e-10 * scale;
-        std::vector<ClipVert> cur(n), next;
-        const float *v = simplex_verts + (size_t)s * n * n;
-        for (int i = 0; i < n; ++i) {
-            cur[i].x.assign(v + (size_t)i * n, v + (size_t)(i + 1) * n);
-            cur[i].tight[0] = cur[i].tight[1] = cur[i].tight[2] = 0;
-            for (int j = 0; j < n; ++j)
-                if (j != i) setbit(cur[i].tight, j);          // lambda_j = 0 at vertex i
+        const int need = n - 2;              // an edge of an (n-1)-polytope: n-2 shared tight constraints
+        static thread_local std::vector<double> dist;
+        dist.resize(nv);
+        bool any_out = false;
+        for (int i = 0; i < nv; ++i) {
+            dist[i] = sgn * (x[(size_t)i * n + a] - bound);
+            any_out = any_out || dist[i] < -eps;
         }
-        const int need = n - 2;                               // an edge of an (n-1)-polytope: n-2 shared tight constraints
-        std::vector<double> dist;
-        for (int a = 0; a < n && !cur.empty(); ++a) {
-            for (int side = 0; side < 2; ++side) {
-                const double bound = side == 0 ? lo[a] : hi[a];
-                const double sgn = side == 0 ? 1.0 : -1.0;    // keep sgn*(x_a - bound) >= 0
-                const int cbit = n + 2 * a + side;
-                dist.resize(cur.size());
-                bool any_out = false;
-                for (size_t i = 0; i < cur.size(); ++i) {
-                    dist[i] = sgn * (cur[i].x[a] - bound);
-                    any_out = any_out || dist[i] < -eps;
-                }
-                if (!any_out) continue;
-                next.clear();
-                for (size_t i = 0; i < cur.size(); ++i)
-                    if (dist[i] >= -eps) {
-                        next.push_back(cur[i]);
-                        if (std::fabs(dist[i]) <= eps) setbit(next.back().tight, cbit);
-                    }
-                for (size_t i = 0; i < cur.size(); ++i) {
-                    if (dist[i] >= -eps) continue;
-                    for (size_t j = 0; j < cur.size(); ++j) {
-                        if (dist[j] <= eps) continue;         // strictly inside partners only
-                        if (popcount3(cur[i].tight, cur[j].tight) < need) continue;
-                        const double t = dist[j] / (dist[j] - dist[i]);
-                        ClipVert nv;
-                        nv.x.resize(n);
-                        for (int k = 0; k < n; ++k) nv.x[k] = cur[j].x[k] + t * (cur[i].x[k] - cur[j].x[k]);
-                        nv.x[a] = bound;
-                        for (int k = 0; k < 3; ++k) nv.tight[k] = cur[i].tight[k] & cur[j].tight[k];
-                        setbit(nv.tight, cbit);
-                        next.push_back(std::move(nv));
-                        if ((int)next.size() > NT_CLIP_MAX_VERTS) { overflow = true; return true; }
+        const size_t v0 = dst.vx.size() / n;
+        for (int i = 0; i < nv; ++i)
+            if (dist[i] >= -eps) {
+                dst.vx.insert(dst.vx.end(), x + (size_t)i * n, x + (size_t)(i + 1) * n);
+                dst.vt.insert(dst.vt.end(), t + (size_t)i * 3, t + (size_t)(i + 1) * 3);
+                if (any_out && std::fabs(dist[i]) <= eps) setbit(&dst.vt[dst.vt.size() - 3], cbit);
+            }
+        if (any_out) {
+            for (int i = 0; i < nv; ++i) {
+                if (dist[i] >= -eps) continue;
+                for (int j = 0; j < nv; ++j) {
+                    if (dist[j] <= eps) continue;             // strictly inside partners only
+                    if (popcount3(t + (size_t)i * 3, t + (size_t)j * 3) < need) continue;
+                    const double w = dist[j] / (dist[j] - dist[i]);
+                    const size_t at = dst.vx.size();
+                    dst.vx.resize(at + n);
+                    for (int k = 0; k < n; ++k) dst.vx[at + k] = x[(size_t)j * n + k] + w * (x[(size_t)i * n + k] - x[(size_t)j * n + k]);
+                    dst.vx[at + a] = bound;
+                    const size_t tt = dst.vt.size();
+                    dst.vt.resize(tt + 3);
+                    for (int k = 0; k < 3; ++k) dst.vt[tt + k] = t[(size_t)i * 3 + k] & t[(size_t)j * 3 + k];
+                    setbit(&dst.vt[tt], cbit);
+                    if ((int)(dst.vx.size() / n - v0) > NT_CLIP_MAX_VERTS) {
+                        dst.vx.resize(v0 * n);
+                        dst.vt.resize(v0 * 3);
+                        return false;
                     }
                 }
-                cur.swap(next);
-                if (cur.empty()) break;
             }
         }
-        if (cur.empty()) return false;
-        for (int k = 0; k < n; ++k) { cmin[k] = std::numeric_limits<double>::infinity(); cmax[k] = -cmin[k]; }
-        for (const ClipVert &c : cur)
-            for (int k = 0; k < n; ++k) { cmin[k] = std::min(cmin[k], c.x[k]); cmax[k] = std::max(cmax[k], c.x[k]); }
+        dst.vert_first.push_back((int)(dst.vx.size() / n));
         return true;
     }
 
-    // extent of item `it` inside the cell; false: not in the cell
-    bool item_bounds(int it, const double *lo, const double *hi, double *cmin, double *cmax) const {
-        const float *blo = item_lo + (size_t)it * n, *bhi = item_hi + (size_t)it * n;
-        for (int k = 0; k < n; ++k) {
-            cmin[k] = std::max<double>(blo[k], lo[k]);
-            cmax[k] = std::min<double>(bhi[k], hi[k]);
-            if (cmin[k] > cmax[k]) return false;
-        }
-        const int s0 = simplex_first[it], s1 = simplex_first[it + 1];
-        if (s0 == s1) return true;                            // solids: bounding box
-        double amin[KD_MAX_DIM], amax[KD_MAX_DIM], smin[KD_MAX_DIM], smax[KD_MAX_DIM];
+    // reference r of `src` restricted to the half-space; appended to `dst` if anything is left
+    void restrict_ref(const Refs &src, int r, int a, int side, double bound, const double *clo, const double *chi, Refs &dst) const {
+        const int it = src.item[r];
+        const double sgn = side == 0 ? 1.0 : -1.0;
+        double bmin[KD_MAX_DIM], bmax[KD_MAX_DIM];
+        bool boxed = src.boxed[r] != 0;
+        const size_t vmark = dst.vx.size(), tmark = dst.vt.size(), smark = dst.vert_first.size();
         bool any = false;
-        for (int s = s0; s < s1; ++s) {
-            bool overflow = false;
-            if (!clip_simplex(s, lo, hi, smin, smax, overflow)) continue;
-            if (overflow) return true;                        // keep the box estimate (conservative)
-            for (int k = 0; k < n; ++k) {
-                amin[k] = any ? std::min(amin[k], smin[k]) : smin[k];
-                amax[k] = any ? std::max(amax[k], smax[k]) : smax[k];
+        if (!boxed) {
+            for (int sl = src.slot_first[r]; sl < src.slot_first[r + 1]; ++sl) {
+                const int f = src.vert_first[sl], nv = src.vert_first[sl + 1] - f;
+                const size_t before = dst.vx.size() / n;
+                if (nv == 0) { dst.vert_first.push_back((int)before); continue; }
+                if (!cut(&src.vx[(size_t)f * n], &src.vt[(size_t)f * 3], nv, a, sgn, bound, n + 2 * a + side, dst)) { boxed = true; break; }
+                for (size_t v = before; v < dst.vx.size() / n; ++v)
+                    for (int k = 0; k < n; ++k) {
+                        const double c = dst.vx[v * n + k];
+                        bmin[k] = any ? std::min(bmin[k], c) : c;
+                        bmax[k] = any ? std::max(bmax[k], c) : c;
+                        if (k == n - 1) any = true;
+                    }
             }
-            any = true;
         }
-        if (!any) return false;
-        for (int k = 0; k < n; ++k) { cmin[k] = std::max(cmin[k], amin[k]); cmax[k] = std::min(cmax[k], amax[k]); }
-        return true;
+        if (boxed) {
+            // bounding box of the item cut to the child cell (conservative)
+            dst.vx.resize(vmark);
+            dst.vt.resize(tmark);
+            dst.vert_first.resize(smark);
+            for (int k = 0; k < n; ++k) {
+                bmin[k] = std::max<double>(item_lo[(size_t)it * n + k], clo[k]);
+                bmax[k] = std::min<double>(item_hi[(size_t)it * n + k], chi[k]);
+                if (bmin[k] > bmax[k]) return;
+            }
+            for (int sl = src.slot_first[r]; sl < src.slot_first[r + 1]; ++sl) dst.vert_first.push_back((int)(dst.vx.size() / n));
+        } else if (!any) {
+            dst.vx.resize(vmark);
+            dst.vt.resize(tmark);
+            dst.vert_first.resize(smark);
+            return;
+        }
+        dst.item.push_back(it);
+        dst.boxed.push_back(boxed ? 1 : 0);
+        dst.cmin.insert(dst.cmin.end(), bmin, bmin + n);
+        dst.cmax.insert(dst.cmax.end(), bmax, bmax + n);
+        dst.slot_first.push_back((int)dst.vert_first.size() - 1);
+    }
+
+    // reference r of `src` unchanged
+    void copy_ref(const Refs &src, int r, Refs &dst) const {
+        dst.item.push_back(src.item[r]);
+        dst.boxed.push_back(src.boxed[r]);
+        dst.cmin.insert(dst.cmin.end(), &src.cmin[(size_t)r * n], &src.cmin[(size_t)r * n] + n);
+        dst.cmax.insert(dst.cmax.end(), &src.cmax[(size_t)r * n], &src.cmax[(size_t)r * n] + n);
+        const int vb = (int)(dst.vx.size() / n);
+        for (int sl = src.slot_first[r]; sl < src.slot_first[r + 1]; ++sl) {
+            const int f = src.vert_first[sl], e = src.vert_first[sl + 1];
+            dst.vx.insert(dst.vx.end(), &src.vx[(size_t)f * n], &src.vx[(size_t)f * n] + (size_t)(e - f) * n);
+            dst.vt.insert(dst.vt.end(), &src.vt[(size_t)f * 3], &src.vt[(size_t)f * 3] + (size_t)(e - f) * 3);
+            dst.vert_first.push_back((int)(dst.vx.size() / n));
+        }
+        (void)vb;
+        dst.slot_first.push_back((int)dst.vert_first.size() - 1);
+    }
+
+    void root_refs(Refs &R) const {
+        R.begin(n);
+        for (int it = 0; it < n_items; ++it) {
+            const int s0 = simplex_first[it], s1 = simplex_first[it + 1];
+            const bool boxed = s0 == s1 || n > KD_CLIP_DIM;
+            R.item.push_back(it);
+            R.boxed.push_back(boxed ? 1 : 0);
+            for (int k = 0; k < n; ++k) { R.cmin.push_back(item_lo[(size_t)it * n + k]); R.cmax.push_back(item_hi[(size_t)it * n + k]); }
+            for (int s = s0; s < s1; ++s) {
+                if (!boxed) {
+                    const float *v = simplex_verts + (size_t)s * n * n;
+                    for (int i = 0; i < n; ++i) {
+                        for (int k = 0; k < n; ++k) R.vx.push_back(v[(size_t)i * n + k]);
+                        uint64_t m[3] = {0, 0, 0};
+                        for (int j = 0; j < n; ++j)
+                            if (j != i) setbit(m, j);          // lambda_j = 0 at vertex i
+                        R.vt.insert(R.vt.end(), m, m + 3);
+                    }
+                }
+                R.vert_first.push_back((int)(R.vx.size() / n));
+            }
+            R.slot_first.push_back((int)R.vert_first.size() - 1);
+        }
     }
 
     static double area(int n, const double *lo, const double *hi) {
@@ -151,20 +248,19 @@ struct Builder {
         return tot;
     }
 
-    int make_leaf(const std::vector<int> &items) {
-        const int idx = (int)node_axis.size();
-        node_axis.push_back(-1);
-        node_split.push_back(0.0f);
-        node_left.push_back((int32_t)leaf_items.size());
-        node_right.push_back((int32_t)items.size());
-        leaf_items.insert(leaf_items.end(), items.begin(), items.end());
+    static int make_leaf(Out &o, const std::vector<int> &items) {
+        const int idx = (int)o.node_axis.size();
+        o.node_axis.push_back(-1);
+        o.node_split.push_back(0.0f);
+        o.node_left.push_back((int32_t)o.leaf_items.size());
+        o.node_right.push_back((int32_t)items.size());
+        o.leaf_items.insert(o.leaf_items.end(), items.begin(), items.end());
         return idx;
     }
 
-    // refs: items in this cell with their extents inside it (cmin/cmax: [ref][n])
-    int build(std::vector<int> &refs, std::vector<double> &cmin, std::vector<double> &cmax, const double *lo, const double *hi, int depth) {
-        const int m = (int)refs.size();
-        if (m <= split_threshold || depth >= max_depth) return make_leaf(refs);
+    int build(Out &o, Refs &R, const double *lo, const double *hi, int depth) {
+        const int m = R.size();
+        if (m <= split_threshold || depth >= max_depth) return make_leaf(o, R.item);
         const double base = area(n, lo, hi);
         double best_cost = std::numeric_limits<double>::infinity();
         int best_axis = -1;
@@ -176,7 +272,7 @@ struct Builder {
                 if (!(hi[axis] > lo[axis])) continue;
                 ev.clear();
                 for (int r = 0; r < m; ++r) {
-                    const double s = cmin[(size_t)r * n + axis], e = cmax[(size_t)r * n + axis];
+                    const double s = R.cmin[(size_t)r * n + axis], e = R.cmax[(size_t)r * n + axis];
                     if (s == e) ev.emplace_back(s, 1);
                     else { ev.emplace_back(s, 2); ev.emplace_back(e, 0); }
                 }
@@ -194,6 +290,7 @@ struct Builder {
                 }
                 int nl = 0, nr = m;
                 size_t i = 0;
+                const double ext = hi[axis] - lo[axis];
                 while (i < ev.size()) {
                     const double pos = ev[i].first;
                     int ends = 0, flats = 0, starts = 0;
@@ -204,7 +301,6 @@ struct Builder {
                         ++i;
                     }
                     nr -= ends + flats;
-                    const double ext = hi[axis] - lo[axis];
                     if (pos > lo[axis] + 1e-7 * scale && pos < hi[axis] - 1e-7 * scale) {
                         // flat primitives lying in the plane go to both sides (the walk picks a side by the ray)
                         const int cl = nl + flats, cr = nr + flats;
@@ -221,57 +317,92 @@ struct Builder {
                 }
             }
         }
-        if (best_axis < 0 || best_cost >= INTERSECTION_COST * m || (best_nl == m && best_nr == m)) return make_leaf(refs);
+        if (best_axis < 0 || best_cost >= INTERSECTION_COST * m || (best_nl == m && best_nr == m)) return make_leaf(o, R.item);
         const float split = (float)best_pos;
         const double sp = (double)split;                       // the kernels compare against the fp32 value
         const double eps = 1e-10 * scale;
         std::vector<double> llo(lo, lo + n), lhi(hi, hi + n), rlo(lo, lo + n), rhi(hi, hi + n);
         lhi[best_axis] = sp;
         rlo[best_axis] = sp;
-        std::vector<int> lrefs, rrefs;
-        std::vector<double> lmin, lmax, rmin, rmax;
-        double bmin[KD_MAX_DIM], bmax[KD_MAX_DIM];
-        for (int r = 0; r < m; ++r) {
-            const double s = cmin[(size_t)r * n + best_axis], e = cmax[(size_t)r * n + best_axis];
-            const bool flat_in_plane = s == e && std::fabs(s - sp) <= eps;
-            if (s < sp - eps || flat_in_plane) {
-                if (e <= sp + eps && !flat_in_plane) {          // entirely left: extents unchanged
-                    lrefs.push_back(refs[r]);
-                    lmin.insert(lmin.end(), &cmin[(size_t)r * n], &cmin[(size_t)r * n] + n);
-                    lmax.insert(lmax.end(), &cmax[(size_t)r * n], &cmax[(size_t)r * n] + n);
-                } else if (item_bounds(refs[r], llo.data(), lhi.data(), bmin, bmax)) {
-                    lrefs.push_back(refs[r]);
-                    lmin.insert(lmin.end(), bmin, bmin + n);
-                    lmax.insert(lmax.end(), bmax, bmax + n);
+        // classify every reference; straddlers are cut by the split plane (big nodes: in parallel, slice by slice)
+        auto classify = [&](int r0, int r1, Refs &L, Refs &Rr) {
+            L.begin(n);
+            Rr.begin(n);
+            for (int r = r0; r < r1; ++r) {
+                const double s = R.cmin[(size_t)r * n + best_axis], e = R.cmax[(size_t)r * n + best_axis];
+                const bool flat_in_plane = s == e && std::fabs(s - sp) <= eps;
+                if (s < sp - eps || flat_in_plane) {
+                    if (e <= sp + eps) copy_ref(R, r, L);                 // entirely left (or flat in the plane)
+                    else restrict_ref(R, r, best_axis, 1, sp, llo.data(), lhi.data(), L);
+                }
+                if (e > sp + eps || flat_in_plane) {
+                    if (s >= sp - eps) copy_ref(R, r, Rr);
+                    else restrict_ref(R, r, best_axis, 0, sp, rlo.data(), rhi.data(), Rr);
                 }
             }
-            if (e > sp + eps || flat_in_plane) {
-                if (s >= sp - eps && !flat_in_plane) {
-                    rrefs.push_back(refs[r]);
-                    rmin.insert(rmin.end(), &cmin[(size_t)r * n], &cmin[(size_t)r * n] + n);
-                    rmax.insert(rmax.end(), &cmax[(size_t)r * n], &cmax[(size_t)r * n] + n);
-                } else if (item_bounds(refs[r], rlo.data(), rhi.data(), bmin, bmax)) {
-                    rrefs.push_back(refs[r]);
-                    rmin.insert(rmin.end(), bmin, bmin + n);
-                    rmax.insert(rmax.end(), bmax, bmax + n);
-                }
-            }
+        };
+        Refs L, Rr;
+        int slices = 1;
+        if (m >= 4096) {
+            int avail = spare_threads.load();
+            const int want = std::min(avail, m / 1024);
+            while (want > 0 && avail >= want && !spare_threads.compare_exchange_weak(avail, avail - want)) {}
+            if (want > 0 && avail >= want) slices = want + 1;
         }
-        if ((int)lrefs.size() == m && (int)rrefs.size() == m) return make_leaf(refs);
-        if (lrefs.empty() && rrefs.empty()) return make_leaf(refs);
-        // free this level's arrays before descending
-        std::vector<int>().swap(refs);
-        std::vector<double>().swap(cmin);
-        std::vector<double>().swap(cmax);
-        const int idx = (int)node_axis.size();
-        node_axis.push_back(best_axis);
-        node_split.push_back(split);
-        node_left.push_back(-1);
-        node_right.push_back(-1);
-        const int l = lrefs.empty() ? -1 : build(lrefs, lmin, lmax, llo.data(), lhi.data(), depth + 1);
-        const int r = rrefs.empty() ? -1 : build(rrefs, rmin, rmax, rlo.data(), rhi.data(), depth + 1);
-        node_left[idx] = l;
-        node_right[idx] = r;
+        if (slices > 1) {
+            std::vector<Refs> ls(slices), rs(slices);
+            std::vector<std::thread> pool;
+            for (int t = 1; t < slices; ++t)
+                pool.emplace_back([&, t] { classify((int)((long long)m * t / slices), (int)((long long)m * (t + 1) / slices), ls[t], rs[t]); });
+            classify(0, (int)((long long)m / slices), ls[0], rs[0]);
+            for (auto &th : pool) th.join();
+            spare_threads.fetch_add(slices - 1);
+            L.begin(n);
+            Rr.begin(n);
+            for (int t = 0; t < slices; ++t) { L.append(ls[t]); ls[t].release(); Rr.append(rs[t]); rs[t].release(); }
+        } else {
+            classify(0, m, L, Rr);
+        }
+        if (L.size() == m && Rr.size() == m) return make_leaf(o, R.item);
+        if (L.size() == 0 && Rr.size() == 0) return make_leaf(o, R.item);
+        R.release();                                            // free this level's arrays before descending
+        const int idx = (int)o.node_axis.size();
+        o.node_axis.push_back(best_axis);
+        o.node_split.push_back(split);
+        o.node_left.push_back(-1);
+        o.node_right.push_back(-1);
+        int l = -1, r = -1;
+        // big subtrees are built side by side: the left one on a new thread into its own arrays, merged afterwards
+        bool forked = false;
+        if (std::min(L.size(), Rr.size()) >= 512) {
+            int avail = spare_threads.load();
+            while (avail > 0 && !spare_threads.compare_exchange_weak(avail, avail - 1)) {}
+            forked = avail > 0;
+        }
+        if (forked) {
+            Out lo_out;
+            int lroot = -1;
+            bool failed = false;
+            std::thread th([&] {
+                try { lroot = build(lo_out, L, llo.data(), lhi.data(), depth + 1); } catch (...) { failed = true; }
+            });
+            try {
+                r = build(o, Rr, rlo.data(), rhi.data(), depth + 1);
+            } catch (...) {
+                th.join();
+                spare_threads.fetch_add(1);
+                throw;
+            }
+            th.join();
+            spare_threads.fetch_add(1);
+            if (failed) throw std::bad_alloc();
+            l = o.append(lo_out, lroot);
+        } else {
+            l = L.size() ? build(o, L, llo.data(), lhi.data(), depth + 1) : -1;
+            r = Rr.size() ? build(o, Rr, rlo.data(), rhi.data(), depth + 1) : -1;
+        }
+        o.node_left[idx] = l;
+        o.node_right[idx] = r;
         return idx;
     }
 };
@@ -288,7 +419,7 @@ T *dup(const std::vector<T> &v) {
 extern "C" {
 
 int nt_kdtree_build(int dimension, int n_items, const float *item_lo, const float *item_hi, const int32_t *simplex_first,
-                    const float *simplex_verts, int max_depth, int split_threshold, nt_kdtree *out) {
+                    const float *simplex_verts, const nt_kdtree_params *params, nt_kdtree *out) {
     if (!out) return NT_E_INVALID;
     std::memset(out, 0, sizeof(*out));
     if (dimension < 1 || dimension > KD_MAX_DIM || n_items < 1 || !item_lo || !item_hi || !simplex_first) return NT_E_INVALID;
@@ -301,8 +432,13 @@ int nt_kdtree_build(int dimension, int n_items, const float *item_lo, const floa
     b.item_hi = item_hi;
     b.simplex_first = simplex_first;
     b.simplex_verts = simplex_verts;
-    b.max_depth = max_depth > 0 ? max_depth : 25;
-    b.split_threshold = split_threshold > 0 ? split_threshold : 2;
+    b.max_depth = params && params->max_depth > 0 ? params->max_depth : 25;
+    b.split_threshold = params && params->split_threshold > 0 ? params->split_threshold : 2;
+    b.TRAVERSAL_COST = params && params->traversal_cost > 0.0f ? params->traversal_cost : 1.0;
+    b.INTERSECTION_COST = params && params->intersection_cost > 0.0f ? params->intersection_cost : 1.0;
+    if (b.max_depth > 64) b.max_depth = 64;
+    b.threads = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    if (const char *e = getenv("NTRACER_BUILD_THREADS")) b.threads = std::max(1, atoi(e));
     const int n = dimension;
     std::vector<double> lo(n, std::numeric_limits<double>::infinity()), hi(n, -std::numeric_limits<double>::infinity());
     double scale = 1.0;
@@ -316,29 +452,22 @@ int nt_kdtree_build(int dimension, int n_items, const float *item_lo, const floa
         }
     b.scale = scale;
     try {
-        std::vector<int> refs;
-        std::vector<double> cmin, cmax;
-        double bmin[KD_MAX_DIM], bmax[KD_MAX_DIM];
-        for (int i = 0; i < n_items; ++i) {
-            if (!b.item_bounds(i, lo.data(), hi.data(), bmin, bmax)) {
-                // degenerate input (e.g. a zero-volume simplex): keep it by its box
-                for (int k = 0; k < n; ++k) { bmin[k] = item_lo[(size_t)i * n + k]; bmax[k] = item_hi[(size_t)i * n + k]; }
-            }
-            refs.push_back(i);
-            cmin.insert(cmin.end(), bmin, bmin + n);
-            cmax.insert(cmax.end(), bmax, bmax + n);
-        }
-        out->root = b.build(refs, cmin, cmax, lo.data(), hi.data(), 0);
+        Refs R;
+        b.root_refs(R);
+        b.spare_threads = b.threads - 1;
+        out->root = b.build(b.top, R, lo.data(), hi.data(), 0);
     } catch (const std::bad_alloc &) {
         return NT_E_NOMEM;
+    } catch (const std::system_error &) {
+        return NT_E_NOMEM;          // could not start a thread
     }
-    out->n_nodes = (int32_t)b.node_axis.size();
-    out->n_leaf_items = (int32_t)b.leaf_items.size();
-    out->node_axis = dup(b.node_axis);
-    out->node_split = dup(b.node_split);
-    out->node_left = dup(b.node_left);
-    out->node_right = dup(b.node_right);
-    out->leaf_items = dup(b.leaf_items);
+    out->n_nodes = (int32_t)b.top.node_axis.size();
+    out->n_leaf_items = (int32_t)b.top.leaf_items.size();
+    out->node_axis = dup(b.top.node_axis);
+    out->node_split = dup(b.top.node_split);
+    out->node_left = dup(b.top.node_left);
+    out->node_right = dup(b.top.node_right);
+    out->leaf_items = dup(b.top.leaf_items);
     out->aabb = (float *)std::malloc(sizeof(float) * 2 * n);
     if (!out->node_axis || !out->node_split || !out->node_left || !out->node_right || !out->leaf_items || !out->aabb) {
         nt_kdtree_free(out);

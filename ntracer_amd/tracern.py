@@ -880,8 +880,8 @@ def build_kdtree(primitives, extra_threads=-1, **kwds):
     max_depth = int(kwds.pop("max_depth", builder.KD_DEFAULT_MAX_DEPTH))
     split_threshold = int(kwds.pop("split_threshold", builder.KD_DEFAULT_SPLIT_THRESHOLD))
     kwds.pop("update_primitives", None)
-    kwds.pop("traversal_cost", None)
-    kwds.pop("intersection_cost", None)
+    traversal_cost = float(kwds.pop("traversal_cost", 0.0) or 0.0)
+    intersection_cost = float(kwds.pop("intersection_cost", 0.0) or 0.0)
     if kwds:
         raise TypeError("unexpected keyword argument %r" % next(iter(kwds)))
     protos = list(primitives)
@@ -897,7 +897,8 @@ def build_kdtree(primitives, extra_threads=-1, **kwds):
            if isinstance(p, TrianglePrototype)]
     other = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v) for p in protos if not isinstance(p, TrianglePrototype)]
     batches, loose = builder.group_batches(tri, BATCH_SIZE, TriangleBatch)
-    lo, hi, root = builder.build_tree(batches + loose + other, KDLeaf, KDBranch, max_depth, split_threshold)
+    lo, hi, root = builder.build_tree(batches + loose + other, KDLeaf, KDBranch, max_depth, split_threshold,
+                                      traversal_cost, intersection_cost)
     return AABB(n, lo, hi), root
 
 

@@ -90,7 +90,7 @@ def test_kdtree_build_abi():
     first = np.arange(4, dtype=np.int32)
     out = _lib.NtKdTree()
     assert L.nt_kdtree_build(n, 3, lo.ctypes.data_as(_lib.f32p), hi.ctypes.data_as(_lib.f32p), first.ctypes.data_as(_lib.i32p),
-                             tris.ctypes.data_as(_lib.f32p), 0, 0, C.byref(out)) == _lib.NT_OK
+                             tris.ctypes.data_as(_lib.f32p), None, C.byref(out)) == _lib.NT_OK
     axis = np.ctypeslib.as_array(out.node_axis, (out.n_nodes,)).copy()
     cnt = np.ctypeslib.as_array(out.node_right, (out.n_nodes,)).copy()
     items = np.ctypeslib.as_array(out.leaf_items, (out.n_leaf_items,)).copy()
@@ -102,11 +102,11 @@ def test_kdtree_build_abi():
     assert np.allclose(box, [0, 0, 0, 6, 6, 5])
     # argument checks
     assert L.nt_kdtree_build(n, 0, lo.ctypes.data_as(_lib.f32p), hi.ctypes.data_as(_lib.f32p), first.ctypes.data_as(_lib.i32p),
-                             tris.ctypes.data_as(_lib.f32p), 0, 0, C.byref(out)) == _lib.NT_E_INVALID
+                             tris.ctypes.data_as(_lib.f32p), None, C.byref(out)) == _lib.NT_E_INVALID
     assert L.nt_kdtree_build(n, 3, hi.ctypes.data_as(_lib.f32p), lo.ctypes.data_as(_lib.f32p), first.ctypes.data_as(_lib.i32p),
-                             tris.ctypes.data_as(_lib.f32p), 0, 0, C.byref(out)) == _lib.NT_E_INVALID     # lo > hi
+                             tris.ctypes.data_as(_lib.f32p), None, C.byref(out)) == _lib.NT_E_INVALID     # lo > hi
     assert L.nt_kdtree_build(n, 3, lo.ctypes.data_as(_lib.f32p), hi.ctypes.data_as(_lib.f32p), first.ctypes.data_as(_lib.i32p),
-                             tris.ctypes.data_as(_lib.f32p), 0, 0, None) == _lib.NT_E_INVALID
+                             tris.ctypes.data_as(_lib.f32p), None, None) == _lib.NT_E_INVALID
 
 
 def test_tree_independence_with_solids_and_loose_triangles():
