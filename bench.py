@@ -305,6 +305,18 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
     bytes_pruned = 16 * 31.2 + 8 * 4.46 + 168 * (4 + 4 * 21) + 4
     res["config4_default_walk_bytes_per_ray"] = round(bytes_pruned)
     res["config4_default_walk_TB_s"] = round(bytes_pruned * 1920 * 1080 / (ms * 1e-3) / 1e12, 2)
+    # the same polytope generated and partitioned on our side (ntracer_amd.polytope + nt_kdtree_build) -- SURVEY 8d's
+    # "build-tree figure"; pixels equal the reference-built scene's except on silhouettes (the reference inflates facets)
+    try:
+        from ntracer_amd import polytope
+        t0 = time.perf_counter()
+        _, own, _ = polytope.build_scene(["5/2", "3", "3"])
+        built_s = time.perf_counter() - t0
+        ms_own = time_scene(own, ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"][sel], g["axes"][sel], 8, 2)
+        res["config4_own_scene"] = {"ms_per_frame": round(ms_own, 3), "Mrays_s": round(1920 * 1080 / ms_own / 1e3, 1),
+                                    "generate_and_build_s": round(built_s, 1)}
+    except Exception as e:          # the headline must not depend on the generator
+        res["config4_own_scene"] = {"error": str(e)[:200]}
     # the same scene with shadows on, one point light and one global light: primary + shadow rays
     n = 4
     sc.add_light(tracern.PointLight(tracern.Vector(n, (8.0, 9.0, -7.0, 3.0)), (60.0, 60.0, 60.0)))

@@ -61,6 +61,37 @@ def from_points_record(points):
     return p1.astype(f32), N.astype(f32), np.asarray(edges, f32)
 
 
+def from_points_records(simplices):
+    """from_points_record for many simplices at once: (count, n, n) points -> (p1 (count,n), face normals (count,n),
+    edge normals (count,n-1,n)), all float32.  Same formulas, batched determinants."""
+    pts = np.asarray(simplices, np.float64)
+    cnt, n, n2 = pts.shape
+    if n != n2:
+        raise ValueError("a simplex in %d dimensions has %d vertices" % (n2, n2))
+
+    def cross_many(vs):                         # vs: (count, n-1, n)
+        r = np.empty((cnt, n))
+        f = 1.0 if n % 2 else -1.0
+        for i in range(n):
+            m = np.delete(vs, i, axis=2)        # (count, n-1 vectors, n-1 coordinates)
+            r[:, i] = f * np.linalg.det(np.swapaxes(m, 1, 2))
+            f = -f
+        return r
+
+    p1 = pts[:, 0, :]
+    vsides = pts[:, 1:, :] - p1[:, None, :]
+    N = cross_many(vsides)
+    square = (N * N).sum(axis=1)
+    if (square == 0.0).any():
+        raise ValueError("the points are not linearly independent")
+    edges = np.empty((cnt, n - 1, n))
+    for i in range(n - 1):
+        vs = vsides.copy()
+        vs[:, i, :] = N
+        edges[:, i, :] = cross_many(vs) / square[:, None]
+    return p1.astype(f32), N.astype(f32), edges.astype(f32)
+
+
 def to_points_array(p1, face_normal, edge_normals):
     """Triangle.to_points as the reference computes it (tracer.hpp:490-506): p1 + cross(edge normals with the
     i-th replaced by the face normal).  NOTE: because of the alternating sign in the generalised cross product

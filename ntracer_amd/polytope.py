@@ -183,20 +183,59 @@ class RegularPolytope(object):
         self._simp[key] = out
         return out
 
-    def simplices(self):
+    def is_star(self):
+        return any(star_component(c) for c in self.schlafli)
+
+    def simplices(self, max_edge=None):
         """The boundary as (count, n, n) float32: n-1-simplices with n vertices each, n = self.dimension.  For a
-        polygon (rank 2, shown in 3-D) the polygon itself is returned, as in the reference (Polygon.hull, :177-181)."""
+        polygon (rank 2, shown in 3-D) the polygon itself is returned, as in the reference (Polygon.hull, :177-181).
+
+        max_edge: bisect simplices until no edge OPPOSITE THE FIRST VERTEX is longer than this.  The cones of a
+        star facet (first vertex = the facet's centre) span the whole facet; cut into needles they can be told
+        apart by a k-d tree.  Default: half the circumradius for star polytopes, no subdivision otherwise."""
         k = self.rank - 1 if self.rank >= 3 else 2
         out = []
         for f in self.faces[k]:
             out.extend(self._simplices(k, f))
-        return np.asarray(out, np.float32)
+        s = np.asarray(out, np.float64)
+        if max_edge is None and self.is_star():
+            max_edge = 0.5 * self.circumradius()
+        if max_edge:
+            s = bisect_bases(s, float(max_edge))
+        return s.astype(np.float32)
 
-    def hull(self, nt, material):
+    def hull(self, nt, material, max_edge=None):
         """-> list of nt.TrianglePrototype, what ``p.hull()`` is in the reference's driver (:569)."""
         if nt.dimension != self.dimension:
             raise ValueError("the polytope needs an NTracer of dimension %d" % self.dimension)
-        return [nt.TrianglePrototype(s, material) for s in self.simplices()]
+        from . import tracern
+        return tracern.triangle_prototypes(self.simplices(max_edge), material)
+
+
+def bisect_bases(simplices, max_edge):
+    """Longest-edge bisection of the face opposite vertex 0 of every simplex ((count, m, n) array) until none of
+    its edges exceeds max_edge; the pieces tile the original simplices exactly."""
+    m = simplices.shape[1]
+    done = []
+    work = np.asarray(simplices, np.float64)
+    while len(work):
+        base = work[:, 1:, :]
+        d = base[:, :, None, :] - base[:, None, :, :]
+        length = np.sqrt((d * d).sum(-1)).reshape(len(work), -1)
+        big = length.max(axis=1) > max_edge
+        done.append(work[~big])
+        w = work[big]
+        if not len(w):
+            break
+        i, j = np.divmod(length[big].argmax(axis=1), m - 1)
+        rows = np.arange(len(w))
+        mid = (w[rows, i + 1] + w[rows, j + 1]) * 0.5
+        a = w.copy()
+        a[rows, i + 1] = mid
+        b = w.copy()
+        b[rows, j + 1] = mid
+        work = np.concatenate([a, b])
+    return np.concatenate(done)
 
 
 def build_scene(schlafli, material=None, cam_dist=4.0, nt=None):
@@ -209,7 +248,9 @@ def build_scene(schlafli, material=None, cam_dist=4.0, nt=None):
     if is_hypercube(comps):
         return nt, nt.BoxScene(), -math.sqrt(n) * cam_dist
     p = RegularPolytope(comps)
-    scene = nt.build_composite_scene(p.hull(nt, material or Material((1, 0.5, 0.5))))
+    hull = p.hull(nt, material or Material((1, 0.5, 0.5)))
+    # big meshes (subdivided star polytopes): a branch step must buy more before the builder takes it
+    scene = nt.build_composite_scene(hull, traversal_cost=4.0 if len(hull) > 20000 else 0.0)
     return nt, scene, -math.sqrt(p.circumradius_square()) * cam_dist
 
 

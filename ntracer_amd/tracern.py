@@ -861,6 +861,25 @@ class TrianglePrototype(PrimitivePrototype):
         self.point_data = tuple(Vector._wrap(p) for p in a)
 
 
+def triangle_prototypes(simplices, material):
+    """Many TrianglePrototypes at once from a (count, n, n) array of vertices (not in the reference: its callers
+    loop over TrianglePrototype(points, material); this is that loop with the records computed in bulk)."""
+    if not isinstance(material, Material):
+        raise TypeError("material must be a Material")
+    a = np.ascontiguousarray(simplices, f32)
+    p1, fn, edges = builder.from_points_records(a)
+    n = a.shape[2]
+    out = []
+    for k in range(len(a)):
+        tp = object.__new__(TrianglePrototype)
+        tp.primitive = Triangle(p1[k], fn[k], edges[k], material)
+        tp.boundary = AABB(n, a[k].min(axis=0), a[k].max(axis=0))
+        tp.face_normal = tp.primitive.face_normal
+        tp.point_data = tuple(Vector._wrap(q) for q in a[k])
+        out.append(tp)
+    return out
+
+
 class SolidPrototype(PrimitivePrototype):
     """tracern.SolidPrototype(type,position,orientation,material) -- tracer.hpp:1375-1382."""
 

@@ -28,7 +28,7 @@ def test_element_counts(symbol, verts, facets, simplices):
     p = polytope.RegularPolytope(symbol)
     assert len(p.vertices) == verts
     assert len(p.faces[p.rank - 1]) == facets
-    s = p.simplices()
+    s = p.simplices(0)                                 # no subdivision: the raw tessellation
     n = p.dimension
     assert s.shape == (simplices, n, n)
     # every vertex on the circumsphere, every 2-face edge at distance 1 from its face centre
@@ -65,7 +65,7 @@ def test_generated_polytope_renders_like_the_references(name, symbol):
     n = int(g["dimension"])
     p = polytope.RegularPolytope(symbol)
     assert abs(-4 * p.circumradius() - float(g["cam_distance"])) < 2e-6 * abs(float(g["cam_distance"]))
-    boundary, root = tracern.build_kdtree(p.hull(NTracer(n), MAT))
+    boundary, root = tracern.build_kdtree(p.hull(NTracer(n), MAT, max_edge=0))
     flat = tracern.CompositeScene._flatten(boundary, root)
     flat["batch_size"] = 4
     w, h = int(g["width"]), int(g["height"])
