@@ -78,6 +78,7 @@ struct DeviceState {
     DevBuf lights;                       // pl_pos | pl_color | gl_dir | gl_color
     unsigned long long lights_version = 0;
     DevBuf framebuffer, cams, probes, stats, counter;
+    DevBuf hits;                         // primary-hit records between the two passes of a lit render
     struct TileOrder { int tx = 0, ty = 0; DevBuf buf; };
     std::vector<std::unique_ptr<TileOrder>> tile_orders;   // packet kernel: tiles sorted centre-out, per tile grid
     int cu_count = 0;
@@ -445,6 +446,8 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     li.cu_count = ds->cu_count;
     li.kernel_choice = 0;
     li.tile_order = nullptr;
+    li.hit_buf = nullptr;
+    li.hit_frames = 0;
     if (const char *kc = getenv("NTRACER_COMPOSITE_KERNEL")) li.kernel_choice = atoi(kc);
     int r;
     if (s->composite) {
@@ -471,6 +474,16 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
                 HIP_TRY(hipMemcpyAsync(ds->cams.p, cam.inl, sizeof(float) * 4 * s->n, hipMemcpyHostToDevice, job.stream));
                 li.persist_cams = (const float *)ds->cams.p;
             }
+        }
+        const bool lit = !s->pl_color.empty() || !s->gl_color.empty() || c.any_reflective;
+        const char *e2p = getenv("NTRACER_TWO_PASS");
+        if (li.persist_cams && !tg.colors_out && lit && !(e2p && atoi(e2p) == 0)) {
+            // scratch for the primary hits of a two-pass render: as many frames as fit in 512 MB, at least one
+            const size_t per_frame = (size_t)16 * tg.width * tg.row_count;
+            size_t frames = std::max<size_t>(1, std::min<size_t>((size_t)job.nframes, ((size_t)512 << 20) / std::max<size_t>(per_frame, 1)));
+            if (int e = ds->hits.ensure(frames * per_frame)) return e;
+            li.hit_buf = ds->hits.p;
+            li.hit_frames = (int)frames;
         }
         const char *eto = getenv("NTRACER_TILE_ORDER");
         if (li.persist_cams && !tg.colors_out && !(eto && atoi(eto) == 0)) {
@@ -681,7 +694,7 @@ void nt_scene_destroy(nt_scene_t *s) {
         (void)hipDeviceSynchronize();
         for (DevBuf *b : {&ds->nodes, &ds->items, &ds->batch_recs, &ds->batch_mats, &ds->tri_recs, &ds->tri_mats, &ds->solid_recs,
                           &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams, &ds->counter,
-                          &ds->probes, &ds->stats})
+                          &ds->probes, &ds->stats, &ds->hits})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
         for (auto &t : ds->tile_orders) t->buf.release();

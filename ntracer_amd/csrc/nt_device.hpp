@@ -44,6 +44,9 @@ struct NtTarget {
     float *colors_out;
     const int *probe_xs, *probe_ys;
     int probe_count;
+    // two-pass renders of lit scenes: primary hits found by the packet kernel, [frame][row][x] records of 16 bytes
+    // (dist, item, lane, -); nullptr otherwise
+    const void *hits;
 };
 
 // Camera rows used by the ray source (camera.hpp:40-45): origin, right, up, forward.
@@ -109,6 +112,8 @@ struct NtLaunchInfo {
     int cu_count;
     int kernel_choice;        // 0: default (packet kernel for lean scenes), 1: persistent per-lane kernel, 2: tile kernel
     const int *tile_order;    // packet kernel: device permutation of the 16x16-pixel quads of the launch (or nullptr)
+    void *hit_buf;            // scratch for two-pass renders: hit_frames * width * rows * 16 bytes (or nullptr)
+    int hit_frames;
 };
 
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);

@@ -141,6 +141,7 @@ __device__ __forceinline__ void store_pixel(uint8_t *p, const NtTarget &tg, uint
 struct PixelRef {
     int x, y;
     long long offset;   // byte offset into dest, or probe index in probe mode
+    long long hit_index; // record index into NtTarget::hits (image mode)
     bool valid;
 };
 
@@ -152,6 +153,7 @@ __device__ __forceinline__ PixelRef locate_pixel(const NtTarget &tg, int px, int
     r.x = 0;
     r.y = 0;
     r.offset = 0;
+    r.hit_index = 0;
     if (tg.colors_out) {
         const int idx = (int)blockIdx.x * (BW * BH) + tid;
         if (idx < tg.probe_count) {
@@ -175,6 +177,7 @@ __device__ __forceinline__ PixelRef locate_pixel(const NtTarget &tg, int px, int
     r.x = x;
     r.y = y;
     r.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+    r.hit_index = ((long long)blockIdx.z * tg.row_count + row) * tg.width + x;
     r.valid = true;
     return r;
 }
@@ -2023,8 +2026,22 @@ __global__ __launch_bounds__(256) void composite_kernel(NtCameraFixed cam, NtCom
         float org[N], right[N], up[N], fwd[N], dir[N];
         load_camera<N>(cam, org, right, up, fwd);
         primary_dir<N>(tg, right, up, fwd, pr.x, pr.y, dir);
-        const Color3 c = composite_color<N, FEAT, STATS>(sc, w, lane, org, dir, st);
-        emit_pixel(tg, pr, c.r, c.g, c.b);
+        Color3 c;
+        bool emit = true;
+        if (FEAT && tg.hits) {
+            // second pass of a lit scene: the primary hit was found by the packet kernel (which has already
+            // written the pixels of the rays that hit nothing)
+            const float4 h = reinterpret_cast<const float4 *>(tg.hits)[pr.hit_index];
+            Hit hit;
+            hit.dist = h.x;
+            hit.item = __float_as_int(h.y);
+            hit.lane = __float_as_int(h.z);
+            emit = hit.item >= 0;
+            if (emit) c = composite_color<N, FEAT, STATS>(sc, w, lane, org, dir, st, &hit);
+        } else {
+            c = composite_color<N, FEAT, STATS>(sc, w, lane, org, dir, st);
+        }
+        if (emit) emit_pixel(tg, pr, c.r, c.g, c.b);
     }
     if (STATS && sc.stats) {
         unsigned int v[8] = {st.rays, st.shadow_rays, st.branches, st.leaves, st.simplex_tests, st.solid_tests, st.hits, st.aabb_enter};
@@ -2281,6 +2298,7 @@ struct PacketArgs {
     int nframes;
     int lds_per_wave;         // bytes
     int frame_major;          // work items numbered frame-major instead of quad-rank-major
+    float4 *hits_out;         // not null: write the primary hits ([frame][row][x]) instead of shading
 };
 
 // The per-lane part of the frame stack is ONE register: bit k of `bothbits` says that the lane entered both
@@ -2560,7 +2578,15 @@ __global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtComposit
         tr[3] = __builtin_amdgcn_ballot_w64(hit.item >= 0);
     }
 #endif
-    if (valid) {
+    bool shade_here = valid;
+    if (!FEAT && pa.hits_out) {
+        // first pass of a lit scene: the shading pass (composite_kernel<N,true,false>) picks the hits up; rays
+        // that hit nothing get their background colour here and are skipped there
+        if (valid) pa.hits_out[((long long)frame * tg.row_count + row) * tg.width + x] =
+            make_float4(hit.dist, __int_as_float(hit.item), __int_as_float(hit.lane), 0.0f);
+        shade_here = valid && hit.item < 0;
+    }
+    if (shade_here) {
         Color3 c;
         if (FEAT) {
             Stats st = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2638,6 +2664,30 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
         pk.nframes = li.nframes;
         pk.order = li.tile_order;
         pk.frame_major = getenv("NTRACER_FRAME_MAJOR") ? atoi(getenv("NTRACER_FRAME_MAJOR")) : 1;
+        pk.hits_out = nullptr;
+        if (feat && li.hit_buf && li.hit_frames > 0) {
+            // Lit scenes in two passes: the lean packet kernel (47 VGPRs, 6 waves/SIMD) finds the primary hits, then
+            // the per-lane shading kernel (256 VGPRs: lights, shadow and reflection rays) starts from them.  One
+            // kernel doing both ran its primary walk at the shading code's occupancy (1 wave/SIMD).
+            pk.lds_per_wave = (int)((size_t)NT_WM * 16 + (size_t)32 * 32);
+            for (int f0 = 0; f0 < li.nframes; f0 += li.hit_frames) {
+                const int cnt = li.nframes - f0 < li.hit_frames ? li.nframes - f0 : li.hit_frames;
+                NtTarget t2 = tg;
+                t2.dest = tg.dest + (long long)f0 * tg.frame_stride;
+                pk.cams = li.persist_cams + (size_t)f0 * 4 * N;
+                pk.nframes = cnt;
+                pk.hits_out = (float4 *)li.hit_buf;
+                hipLaunchKernelGGL((composite_packet<N, 32, false>), dim3((unsigned)((long long)pk.quads * cnt)), dim3(256),
+                                   (size_t)4 * pk.lds_per_wave, s, sc, t2, pk);
+                t2.hits = li.hit_buf;
+                NtCameraFixed c2 = cf;
+                c2.buf = li.persist_cams + (size_t)f0 * 4 * N;
+                dim3 g2;
+                grid_for(t2, 16, 16, cnt, g2);
+                hipLaunchKernelGGL((composite_kernel<N, true, false>), g2, dim3(256), lds, s, c2, sc, t2);
+            }
+            return 0;
+        }
         const dim3 pgrid((unsigned)((long long)pk.quads * li.nframes));
 #define NT_PACKET_CASE(D)                                                                                   \
     if (sc.stack_depth <= D) {                                                                              \
