@@ -88,6 +88,9 @@ struct DeviceState {
 struct Format {                          // validated image_format (render.cpp:167-172)
     int width = 0, height = 0, pitch = 0, bpp = 0, reversed = 0;
     int pack_mode = NT_PACK_GENERIC;
+    // "plain RGB" layouts (every live channel is exactly one of r, g, b, same bit size, one 32-bit word): the three
+    // multipliers place a quantised component into all the fields that carry it; 0 bits = not such a layout
+    uint32_t plain_bits = 0, plain_maxval = 0, plain_mul[3] = {0, 0, 0};
     std::vector<NtChanDev> chans;        // live channels only (all-zero channels contribute no bits)
 };
 
@@ -159,6 +162,25 @@ int parse_format(const nt_image_format *f, Format &out) {
     out.pack_mode = NT_PACK_GENERIC;
     if (out.chans.size() <= 4 && bits <= 32) out.pack_mode = NT_PACK_WORD32;
     else if (out.chans.size() <= 4 && bits <= 64) out.pack_mode = NT_PACK_WORD64;
+    if (out.pack_mode == NT_PACK_WORD32 && !out.chans.empty()) {
+        bool plain = true;
+        uint32_t mul[3] = {0, 0, 0};
+        for (const NtChanDev &d : out.chans) {
+            const float f[3] = {d.f_r, d.f_g, d.f_b};
+            int comp = -1, ones = 0, zeros = 0;
+            for (int k = 0; k < 3; ++k) {
+                if (f[k] == 1.0f) { comp = k; ++ones; }
+                else if (f[k] == 0.0f && !std::signbit(f[k])) ++zeros;
+            }
+            if (ones != 1 || zeros != 2 || d.f_c != 0.0f || std::signbit(d.f_c) || d.tfloat || d.bits != out.chans[0].bits) { plain = false; break; }
+            mul[comp] |= 1u << (32u - d.offset - d.bits);
+        }
+        if (plain) {
+            out.plain_bits = out.chans[0].bits;
+            out.plain_maxval = out.chans[0].maxval;
+            for (int k = 0; k < 3; ++k) out.plain_mul[k] = mul[k];
+        }
+    }
     if (f->width < 1 || f->height < 1) return fail(NT_E_INVALID, "width and height must be at least 1");
     if (f->pitch < 0) return fail(NT_E_INVALID, "pitch cannot be negative");
     out.width = f->width;
@@ -421,6 +443,9 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         tg.chans = chans;
         tg.nchannels = (int)f.chans.size();
         tg.pack_mode = f.pack_mode;
+        tg.plain_bits = f.plain_bits;
+        tg.plain_maxval = f.plain_maxval;
+        for (int k = 0; k < 3; ++k) tg.plain_mul[k] = f.plain_mul[k];
         tg.bpp = f.bpp;
         tg.reversed = f.reversed;
         tg.pitch = f.pitch;
@@ -437,6 +462,12 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     cam.buf = job.cam_buf;
     cam.n = s->n;
     if (!job.cam_buf) pack_camera(s->n, s->origin.data(), s->axes.data(), cam.inl);
+    cam.osq = 0.0f;
+    {
+        double q = 0.0;
+        for (int k = 0; k < s->n; ++k) q += (double)s->origin[k] * (double)s->origin[k];
+        cam.osq = (float)q;
+    }
     NtLaunchInfo li;
     li.n = s->n;
     li.nframes = job.nframes;
@@ -882,9 +913,13 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
     const int n = s->n;
-    std::vector<float> packed((size_t)nframes * 4 * n);
-    for (int fidx = 0; fidx < nframes; ++fidx)
+    std::vector<float> packed((size_t)nframes * 4 * n + (size_t)nframes);
+    for (int fidx = 0; fidx < nframes; ++fidx) {
         pack_camera(n, origins + (size_t)fidx * n, axes + (size_t)fidx * n * n, packed.data() + (size_t)fidx * 4 * n);
+        double q = 0.0;
+        for (int k = 0; k < n; ++k) q += (double)origins[(size_t)fidx * n + k] * (double)origins[(size_t)fidx * n + k];
+        packed[(size_t)nframes * 4 * n + fidx] = (float)q;          // |origin|^2 per frame, after the cameras
+    }
     // a camera table that earlier launches may still read must not be overwritten: grow-only buffer,
     // refilled only after the stream that used it has drained (same-stream ordering)
     if (int r = ds->cams.ensure(packed.size() * sizeof(float))) return r;

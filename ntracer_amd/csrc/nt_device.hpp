@@ -35,6 +35,9 @@ struct NtTarget {
     const NtChanDev *chans;
     int nchannels, bpp, reversed, pitch;
     int pack_mode;            // NT_PACK_*; channels whose value is identically 0 are dropped from `chans`
+    // plain RGB layouts in one dword (RGBX8, BGRA8, ...): plain_bits != 0, and component k goes to the fields
+    // plain_mul[k] marks (a quantised component times plain_mul[k] is that component shifted into all of them)
+    uint32_t plain_bits, plain_maxval, plain_mul[3];
     int width, height;        // view size: set_view_size(w,h) (tracer.hpp:65-69)
     float half_w, half_h, fovI;
     int band_rank, band_world, band_rows, compact;
@@ -52,14 +55,18 @@ struct NtTarget {
 // Camera rows used by the ray source (camera.hpp:40-45): origin, right, up, forward.
 // Either inline in the kernel arguments (single frame) or from a device buffer
 // [frame][4][n] (multi-frame launches).
+// |origin|^2 travels with the camera (BoxScene's circumsphere rejection needs it and it is the same for every
+// ray): `osq` for the inline camera, one float per frame after the last camera of a table.
 struct NtCamera {
-    const float *buf;         // nullptr => use `inl`
+    const float *buf;         // nullptr => use `inl`; else [nframes][4][n] followed by [nframes] |origin|^2
     int n;
+    float osq;
     float inl[4 * NT_DEV_MAX_DIM];
 };
 struct NtCameraFixed {        // N <= 8: 4*8 floats inline
     const float *buf;
     int n;
+    float osq;
     float inl[4 * NT_DEV_MAX_FIXED];
 };
 

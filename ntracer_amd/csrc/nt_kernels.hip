@@ -213,6 +213,22 @@ __device__ __forceinline__ void emit_pixel(const NtTarget &tg, const PixelRef &p
     store_pixel(p, tg, hi, lo);
 }
 
+// BoxScene colours always have g == b (tracer.hpp:107-113: shade*(1,.5,.5), (i,i,i) or (0,-i,-i)).  For plain RGB
+// layouts in one aligned dword the channel value is the component itself -- (0*g + 0*b) + (1*r + 0) == r -- so
+// the G and B fields share one quantisation; same bits as emit_pixel, fewer instructions.
+__device__ __forceinline__ bool plain_rgb(const NtTarget &tg) {
+    return tg.plain_bits != 0u && tg.bpp == 4 && tg.aligned4 && !tg.colors_out;
+}
+__device__ __forceinline__ uint32_t plain_quantize(const NtTarget &tg, float v) {
+    v = v > 0.0f ? v : 0.0f;     // simd::clamp, as in channel_value
+    v = v < 1.0f ? v : 1.0f;
+    return quantize(v, tg.plain_maxval, tg.plain_bits);
+}
+__device__ __forceinline__ void emit_plain(const NtTarget &tg, const PixelRef &pr, uint32_t qr, uint32_t qgb) {
+    const uint32_t w = qr * tg.plain_mul[0] + qgb * (tg.plain_mul[1] + tg.plain_mul[2]);
+    *reinterpret_cast<uint32_t *>(tg.dest + pr.offset) = tg.reversed ? w : bswap32(w);
+}
+
 // --------------------------------------------------------------------------------------
 // BoxScene, compile-time N (fixed_geometry.hpp -> registers)
 // --------------------------------------------------------------------------------------
@@ -274,10 +290,10 @@ __device__ __forceinline__ void primary_dir(const NtTarget &tg, const float (&ri
 // may hit never normalise more than dir[0], the one component the background colour needs: that saves N-1 of
 // the N IEEE divisions for ~85 % of the rays of the 6-D benchmark frames.
 template <int N>
-__device__ __forceinline__ bool box_may_hit(const float (&o)[N], const float (&v)[N], float sq) {
-    float osq = o[0] * o[0], ov = o[0] * v[0];
+__device__ __forceinline__ bool box_may_hit(const float (&o)[N], const float (&v)[N], float sq, float osq) {
+    float ov = o[0] * v[0];
 #pragma unroll
-    for (int j = 1; j < N; ++j) { osq += o[j] * o[j]; ov += o[j] * v[j]; }
+    for (int j = 1; j < N; ++j) ov += o[j] * v[j];
     const float rad2 = (float)N * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
 #ifdef NT_EXP_SKIP_SLABS
     return false;
@@ -367,14 +383,27 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
 #pragma unroll
     for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
     const float len = sqrtf(sq);
-    const bool maybe = box_may_hit<N>(org, dir, sq);
+    // |origin|^2 from the host (uniform; only the conservative rejection uses it)
+    const float osq = cam.buf ? cam.buf[(size_t)gridDim.z * 4 * N + blockIdx.z] : cam.osq;
+    const bool maybe = box_may_hit<N>(org, dir, sq, osq);
     float r, g, b;
     if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) {
-        box_background(dir[0] / len, r, g, b);
+        const float in = dir[0] / len;
+        if (plain_rgb(tg)) {
+            // (i,i,i) or (0,-i,-i): one magnitude, one quantisation
+            const uint32_t q = plain_quantize(tg, fabsf(in));
+            emit_plain(tg, pr, in > 0.0f ? q : 0u, q);
+            return;
+        }
+        box_background(in, r, g, b);
     } else {
 #pragma unroll
         for (int j = 0; j < N; ++j) dir[j] = dir[j] / len;
         box_color<N>(org, dir, maybe, r, g, b);
+        if (plain_rgb(tg)) {
+            emit_plain(tg, pr, plain_quantize(tg, r), plain_quantize(tg, g));       // g == b
+            return;
+        }
     }
     emit_pixel(tg, pr, r, g, b);
 }
@@ -413,12 +442,9 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
     // Same exact pruning as box_color<N> (see there): circumsphere rejection per wave on the unnormalised
     // direction (box_may_hit), then only the faces in a near-tie with the last-reached candidate K get the
     // division and the n-1 checks.  Waves that cannot hit normalise dir[0] only.
-    float osq = 0.0f, ov = 0.0f;
-    for (int j = 0; j < n; ++j) {
-        const float oj = c[j];
-        osq = fmaf(oj, oj, osq);
-        ov = fmaf(oj, dir[j * 256], ov);
-    }
+    const float osq = cam.buf ? cam.buf[(size_t)gridDim.z * 4 * n + blockIdx.z] : cam.osq;
+    float ov = 0.0f;
+    for (int j = 0; j < n; ++j) ov = fmaf(c[j], dir[j * 256], ov);
     const float rad2 = (float)n * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
     const bool maybe = !((osq - rad2 * 1.0001f - 1e-5f * osq) * sq > ov * ov * 1.0001f);   // FMA rounding covered by the margins
     const bool wave_maybe = __builtin_amdgcn_ballot_w64(maybe) != 0ull;
@@ -476,6 +502,10 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
         const float in = dir[0];
         if (in > 0.0f) { r = in; g = in; b = in; }
         else { r = 0.0f; g = -in; b = -in; }
+    }
+    if (plain_rgb(tg)) {
+        emit_plain(tg, pr, plain_quantize(tg, r), plain_quantize(tg, g));            // g == b
+        return;
     }
     emit_pixel(tg, pr, r, g, b);
 }
@@ -2626,6 +2656,7 @@ template <int N>
 int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg) {
     NtCameraFixed cf;
     cf.buf = cam.buf;
+    cf.osq = cam.osq;
     cf.n = N;
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];
     dim3 grid;
@@ -2638,6 +2669,7 @@ template <int N>
 int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg) {
     NtCameraFixed cf;
     cf.buf = cam.buf;
+    cf.osq = cam.osq;
     cf.n = N;
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];
     dim3 grid;
