@@ -314,6 +314,16 @@ int chan_table(DeviceState *ds, const Format &f, const NtChanDev *&dev_ptr) {
     return NT_OK;
 }
 
+// |o|^2, o.right, o.up, o.forward (see NtCamera)
+void camera_dots(int n, const float *origin, const float *axes, float out[4]) {
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < n; ++k) {
+        q[0] += (double)origin[k] * origin[k];
+        for (int r = 0; r < 3; ++r) q[1 + r] += (double)origin[k] * axes[(size_t)r * n + k];
+    }
+    for (int r = 0; r < 4; ++r) out[r] = (float)q[r];
+}
+
 // camera rows the ray source needs: origin, right, up, forward (camera.hpp:40-45)
 void pack_camera(int n, const float *origin, const float *axes, float *out) {
     std::memcpy(out, origin, sizeof(float) * n);
@@ -462,12 +472,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     cam.buf = job.cam_buf;
     cam.n = s->n;
     if (!job.cam_buf) pack_camera(s->n, s->origin.data(), s->axes.data(), cam.inl);
-    cam.osq = 0.0f;
-    {
-        double q = 0.0;
-        for (int k = 0; k < s->n; ++k) q += (double)s->origin[k] * (double)s->origin[k];
-        cam.osq = (float)q;
-    }
+    camera_dots(s->n, s->origin.data(), s->axes.data(), cam.odots);
     NtLaunchInfo li;
     li.n = s->n;
     li.nframes = job.nframes;
@@ -913,12 +918,10 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
     const int n = s->n;
-    std::vector<float> packed((size_t)nframes * 4 * n + (size_t)nframes);
+    std::vector<float> packed((size_t)nframes * 4 * n + (size_t)nframes * 4);
     for (int fidx = 0; fidx < nframes; ++fidx) {
         pack_camera(n, origins + (size_t)fidx * n, axes + (size_t)fidx * n * n, packed.data() + (size_t)fidx * 4 * n);
-        double q = 0.0;
-        for (int k = 0; k < n; ++k) q += (double)origins[(size_t)fidx * n + k] * (double)origins[(size_t)fidx * n + k];
-        packed[(size_t)nframes * 4 * n + fidx] = (float)q;          // |origin|^2 per frame, after the cameras
+        camera_dots(n, origins + (size_t)fidx * n, axes + (size_t)fidx * n * n, packed.data() + (size_t)nframes * 4 * n + (size_t)fidx * 4);
     }
     // a camera table that earlier launches may still read must not be overwritten: grow-only buffer,
     // refilled only after the stream that used it has drained (same-stream ordering)

@@ -55,18 +55,19 @@ struct NtTarget {
 // Camera rows used by the ray source (camera.hpp:40-45): origin, right, up, forward.
 // Either inline in the kernel arguments (single frame) or from a device buffer
 // [frame][4][n] (multi-frame launches).
-// |origin|^2 travels with the camera (BoxScene's circumsphere rejection needs it and it is the same for every
-// ray): `osq` for the inline camera, one float per frame after the last camera of a table.
+// Four ray-independent dot products travel with the camera for BoxScene's circumsphere rejection (conservative,
+// not part of the exact predicate): |origin|^2, origin.right, origin.up, origin.forward -- `odots` for the inline
+// camera, four floats per frame after the last camera of a table.
 struct NtCamera {
-    const float *buf;         // nullptr => use `inl`; else [nframes][4][n] followed by [nframes] |origin|^2
+    const float *buf;         // nullptr => use `inl`; else [nframes][4][n] followed by [nframes][4] dot products
     int n;
-    float osq;
+    float odots[4];
     float inl[4 * NT_DEV_MAX_DIM];
 };
 struct NtCameraFixed {        // N <= 8: 4*8 floats inline
     const float *buf;
     int n;
-    float osq;
+    float odots[4];
     float inl[4 * NT_DEV_MAX_FIXED];
 };
 

@@ -289,12 +289,11 @@ __device__ __forceinline__ void primary_dir(const NtTarget &tg, const float (&ri
 // not bit-exact -- it only decides whether the exact predicate is evaluated at all.  Waves in which no lane
 // may hit never normalise more than dir[0], the one component the background colour needs: that saves N-1 of
 // the N IEEE divisions for ~85 % of the rays of the 6-D benchmark frames.
-template <int N>
-__device__ __forceinline__ bool box_may_hit(const float (&o)[N], const float (&v)[N], float sq, float osq) {
-    float ov = o[0] * v[0];
-#pragma unroll
-    for (int j = 1; j < N; ++j) ov += o[j] * v[j];
-    const float rad2 = (float)N * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
+// dots: |o|^2, o.right, o.up, o.forward (host); v = forward + right*sx - up*sy, so o.v follows from three of them
+__device__ __forceinline__ bool box_may_hit(int n, const float *dots, float sx, float sy, float sq) {
+    const float osq = dots[0];
+    const float ov = fmaf(-dots[2], sy, fmaf(dots[1], sx, dots[3]));
+    const float rad2 = (float)n * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
 #ifdef NT_EXP_SKIP_SLABS
     return false;
 #else
@@ -383,9 +382,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
 #pragma unroll
     for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
     const float len = sqrtf(sq);
-    // |origin|^2 from the host (uniform; only the conservative rejection uses it)
-    const float osq = cam.buf ? cam.buf[(size_t)gridDim.z * 4 * N + blockIdx.z] : cam.osq;
-    const bool maybe = box_may_hit<N>(org, dir, sq, osq);
+    const bool maybe = box_may_hit(N, cam.buf ? cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4 : cam.odots, sx, sy, sq);
     float r, g, b;
     if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) {
         const float in = dir[0] / len;
@@ -442,9 +439,9 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
     // Same exact pruning as box_color<N> (see there): circumsphere rejection per wave on the unnormalised
     // direction (box_may_hit), then only the faces in a near-tie with the last-reached candidate K get the
     // division and the n-1 checks.  Waves that cannot hit normalise dir[0] only.
-    const float osq = cam.buf ? cam.buf[(size_t)gridDim.z * 4 * n + blockIdx.z] : cam.osq;
-    float ov = 0.0f;
-    for (int j = 0; j < n; ++j) ov = fmaf(c[j], dir[j * 256], ov);
+    const float *dots = cam.buf ? cam.buf + (size_t)gridDim.z * 4 * n + (size_t)blockIdx.z * 4 : cam.odots;
+    const float osq = dots[0];
+    const float ov = fmaf(-dots[2], sy, fmaf(dots[1], sx, dots[3]));
     const float rad2 = (float)n * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
     const bool maybe = !((osq - rad2 * 1.0001f - 1e-5f * osq) * sq > ov * ov * 1.0001f);   // FMA rounding covered by the margins
     const bool wave_maybe = __builtin_amdgcn_ballot_w64(maybe) != 0ull;
@@ -2656,7 +2653,7 @@ template <int N>
 int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg) {
     NtCameraFixed cf;
     cf.buf = cam.buf;
-    cf.osq = cam.osq;
+    for (int k = 0; k < 4; ++k) cf.odots[k] = cam.odots[k];
     cf.n = N;
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];
     dim3 grid;
@@ -2669,7 +2666,7 @@ template <int N>
 int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg) {
     NtCameraFixed cf;
     cf.buf = cam.buf;
-    cf.osq = cam.osq;
+    for (int k = 0; k < 4; ++k) cf.odots[k] = cam.odots[k];
     cf.n = N;
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];
     dim3 grid;
