@@ -382,7 +382,14 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
 #pragma unroll
     for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
     const float len = sqrtf(sq);
-    const bool maybe = box_may_hit(N, cam.buf ? cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4 : cam.odots, sx, sy, sq);
+    float dots[4];
+    if (cam.buf) {
+        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
+    } else {
+        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
+    }
+    const bool maybe = box_may_hit(N, dots, sx, sy, sq);
     float r, g, b;
     if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) {
         const float in = dir[0] / len;
@@ -439,7 +446,13 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
     // Same exact pruning as box_color<N> (see there): circumsphere rejection per wave on the unnormalised
     // direction (box_may_hit), then only the faces in a near-tie with the last-reached candidate K get the
     // division and the n-1 checks.  Waves that cannot hit normalise dir[0] only.
-    const float *dots = cam.buf ? cam.buf + (size_t)gridDim.z * 4 * n + (size_t)blockIdx.z * 4 : cam.odots;
+    float dots[4];
+    if (cam.buf) {
+        const float *dp = cam.buf + (size_t)gridDim.z * 4 * n + (size_t)blockIdx.z * 4;
+        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
+    } else {
+        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
+    }
     const float osq = dots[0];
     const float ov = fmaf(-dots[2], sy, fmaf(dots[1], sx, dots[3]));
     const float rad2 = (float)n * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
