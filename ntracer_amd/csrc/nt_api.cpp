@@ -79,6 +79,7 @@ struct DeviceState {
     unsigned long long lights_version = 0;
     DevBuf framebuffer, cams, probes, stats, counter;
     DevBuf hits;                         // primary-hit records between the two passes of a lit render
+    DevBuf numer;                        // packet kernel: -(N.o + d) per (frame, simplex)
     struct TileOrder { int tx = 0, ty = 0; DevBuf buf; };
     std::vector<std::unique_ptr<TileOrder>> tile_orders;   // packet kernel: tiles sorted centre-out, per tile grid
     int cu_count = 0;
@@ -372,6 +373,7 @@ void fill_composite(const nt_scene *s, const DeviceState *ds, NtCompositeDev &c,
     c.all_opaque = s->all_opaque;
     c.any_reflective = s->any_reflective;
     c.has_scalar_prims = s->has_scalar;
+    c.n_batches = s->n_batches;
     c.stats = stats ? (unsigned long long *)ds->stats.p : nullptr;
 }
 
@@ -484,6 +486,8 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     li.tile_order = nullptr;
     li.hit_buf = nullptr;
     li.hit_frames = 0;
+    li.numer_buf = nullptr;
+    li.numer_frames = 0;
     if (const char *kc = getenv("NTRACER_COMPOSITE_KERNEL")) li.kernel_choice = atoi(kc);
     int r;
     if (s->composite) {
@@ -510,6 +514,15 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
                 HIP_TRY(hipMemcpyAsync(ds->cams.p, cam.inl, sizeof(float) * 4 * s->n, hipMemcpyHostToDevice, job.stream));
                 li.persist_cams = (const float *)ds->cams.p;
             }
+        }
+        const char *enum_ = getenv("NTRACER_NUMERATORS");
+        if (li.persist_cams && !tg.colors_out && s->n_batches > 0 && !(enum_ && atoi(enum_) == 0)) {
+            // plane numerators of the packet kernel: as many frames as fit in 256 MB, at least one
+            const size_t per_frame = (size_t)s->n_batches * NT_BATCH_SIZE * sizeof(float);
+            const size_t frames = std::max<size_t>(1, std::min<size_t>((size_t)job.nframes, ((size_t)256 << 20) / per_frame));
+            if (int e = ds->numer.ensure(frames * per_frame)) return e;
+            li.numer_buf = (float *)ds->numer.p;
+            li.numer_frames = (int)frames;
         }
         const bool lit = !s->pl_color.empty() || !s->gl_color.empty() || c.any_reflective;
         const char *e2p = getenv("NTRACER_TWO_PASS");
@@ -730,7 +743,7 @@ void nt_scene_destroy(nt_scene_t *s) {
         (void)hipDeviceSynchronize();
         for (DevBuf *b : {&ds->nodes, &ds->items, &ds->batch_recs, &ds->batch_mats, &ds->tri_recs, &ds->tri_mats, &ds->solid_recs,
                           &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams, &ds->counter,
-                          &ds->probes, &ds->stats, &ds->hits})
+                          &ds->probes, &ds->stats, &ds->hits, &ds->numer})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
         for (auto &t : ds->tile_orders) t->buf.release();

@@ -104,6 +104,7 @@ struct NtCompositeDev {
     int all_opaque;           // every material has opacity >= 1
     int any_reflective;
     int has_scalar_prims;     // leaves hold unbatched triangles or solids
+    int n_batches;
     int prune;                // 1: closest-hit walks drop subtrees that start clearly beyond the current hit (nt_beyond_hit)
     unsigned long long *stats;  // nullptr or 8 counters (nt_stats order)
 };
@@ -122,6 +123,8 @@ struct NtLaunchInfo {
     const int *tile_order;    // packet kernel: device permutation of the 16x16-pixel quads of the launch (or nullptr)
     void *hit_buf;            // scratch for two-pass renders: hit_frames * width * rows * 16 bytes (or nullptr)
     int hit_frames;
+    float *numer_buf;         // scratch for the packet kernel's plane numerators: numer_frames * n_batches * 4 floats
+    int numer_frames;
 };
 
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);

@@ -2339,6 +2339,8 @@ struct PacketArgs {
     int lds_per_wave;         // bytes
     int frame_major;          // work items numbered frame-major instead of quad-rank-major
     float4 *hits_out;         // not null: write the primary hits ([frame][row][x]) instead of shading
+    const float *numer;       // not null: [frame][batch][4] plane numerators -(N.o + d) (packet_numerators)
+    int n_batches;
 };
 
 // The per-lane part of the frame stack is ONE register: bit k of `bothbits` says that the lane entered both
@@ -2350,6 +2352,22 @@ struct PacketArgs {
 // FEAT = true: the packet walk finds the primary hits (batches only), then every lane shades its hit with the
 // general base_color -- lights, shadow rays (per-lane _occludes walks), reflections (per-lane closest-hit walks);
 // those secondary walks need the per-lane LDS stack + ray table, placed after the packet's own LDS.
+// Plane numerators for the packet kernel: t = -(N.o + d) / (N.dir) (tracer.hpp:560-563) and primary rays share o,
+// so the numerator is computed once per (frame, simplex) here -- with exactly the operations the kernel would
+// use per lane -- and fetched with the batch's other scalars: a quarter of stage 1's VALU work.
+template <int N>
+__global__ __launch_bounds__(256) void packet_numerators(NtCompositeDev sc, const float *cams, float *out) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;            // simplex index (batch*4 + lane)
+    const long long total = (long long)sc.n_batches * NT_DEV_BATCH;
+    if (k >= total) return;
+    const float *rec = sc.batch_recs + (size_t)k * sc.rec_stride;
+    const float *o = cams + (size_t)blockIdx.y * 4 * N;
+    float no = rec[1] * o[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) no = no + rec[1 + j] * o[j];
+    out[(size_t)blockIdx.y * total + k] = -(no + rec[0]);
+}
+
 // Wave-level mailbox of the packet kernel: the walk is wave-uniform, so "which lanes have already tested batch X"
 // is one 64-bit mask per batch.  NT_WM direct-mapped entries (tag, mask) replace the per-lane 16-slot mailbox: the
 // lookup is one LDS read of a uniform address, and 256 entries remember a ray's whole path through all but the
@@ -2402,6 +2420,7 @@ __global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtComposit
     int *ustack = wm + NT_WM * 4;                 // [DEPTH][8]: far node, far-lane mask lo, hi, split, axis
 
     // ---- this wave's tile
+    const float *numer = pa.numer ? pa.numer + (size_t)frame * pa.n_batches * NT_DEV_BATCH : nullptr;     // uniform
     const int quad = pa.order ? pa.order[rank] : rank;
     const int qy = quad / pa.quads_x, qx = quad - qy * pa.quads_x;
     const int tx = qx * 2 + (wv & 1), ty = qy * 2 + (wv >> 1);
@@ -2474,10 +2493,16 @@ __global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtComposit
                         float denom = rec[1] * d[0];
 #pragma unroll
                         for (int k = 1; k < N; ++k) denom = denom + rec[1 + k] * d[k];
-                        float no = rec[1] * o[0];
+                        float num;
+                        if (numer) {
+                            num = numer[(size_t)(cur >> 2) * NT_DEV_BATCH + l];
+                        } else {
+                            float no = rec[1] * o[0];
 #pragma unroll
-                        for (int k = 1; k < N; ++k) no = no + rec[1 + k] * o[k];
-                        tl[l] = -(no + rec[0]) / denom;
+                            for (int k = 1; k < N; ++k) no = no + rec[1 + k] * o[k];
+                            num = -(no + rec[0]);
+                        }
+                        tl[l] = num / denom;
                         ok1[l] = denom != 0.0f && tl[l] >= 0.0f;
                     }
                     doit = false;
@@ -2707,20 +2732,42 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
         pk.order = li.tile_order;
         pk.frame_major = getenv("NTRACER_FRAME_MAJOR") ? atoi(getenv("NTRACER_FRAME_MAJOR")) : 1;
         pk.hits_out = nullptr;
-        if (feat && li.hit_buf && li.hit_frames > 0) {
+        pk.numer = nullptr;
+        pk.n_batches = sc.n_batches;
+        const bool two_pass = feat && li.hit_buf && li.hit_frames > 0;
+        const bool single_feat = feat && !two_pass;
+        // frames per launch: what the scratch buffers (primary hits, plane numerators) hold
+        int chunk = li.nframes;
+        if (two_pass && li.hit_frames < chunk) chunk = li.hit_frames;
+        if (li.numer_buf && li.numer_frames > 0 && li.numer_frames < chunk) chunk = li.numer_frames;
+        const size_t lds_lean = (size_t)NT_WM * 16 + (size_t)32 * 32;
+        const size_t lds_feat = (size_t)64 * ((size_t)N * 8 + (size_t)sc.stack_depth * 4 + NT_MBOX * 4) + NT_WM * 16 + (size_t)32 * 32;
+        for (int f0 = 0; f0 < li.nframes; f0 += chunk) {
+            const int cnt = li.nframes - f0 < chunk ? li.nframes - f0 : chunk;
+            NtTarget t2 = tg;
+            t2.dest = tg.dest + (long long)f0 * tg.frame_stride;
+            pk.cams = li.persist_cams + (size_t)f0 * 4 * N;
+            pk.nframes = cnt;
+            if (li.numer_buf && li.numer_frames > 0 && sc.n_batches > 0) {
+                // -(N.o + d) of every simplex for every camera of the chunk: the same for all rays of a frame
+                const long long total = (long long)sc.n_batches * NT_DEV_BATCH;
+                hipLaunchKernelGGL((packet_numerators<N>), dim3((unsigned)((total + 255) / 256), (unsigned)cnt), dim3(256), 0, s,
+                                   sc, pk.cams, li.numer_buf);
+                pk.numer = li.numer_buf;
+            }
+            const dim3 pgrid((unsigned)((long long)pk.quads * cnt));
+            if (single_feat) {
+                pk.lds_per_wave = (int)lds_feat;
+                hipLaunchKernelGGL((composite_packet<N, 32, true>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, t2, pk);
+                continue;
+            }
             // Lit scenes in two passes: the lean packet kernel (47 VGPRs, 6 waves/SIMD) finds the primary hits, then
-            // the per-lane shading kernel (256 VGPRs: lights, shadow and reflection rays) starts from them.  One
+            // the per-lane shading kernel (250 VGPRs: lights, shadow and reflection rays) starts from them.  One
             // kernel doing both ran its primary walk at the shading code's occupancy (1 wave/SIMD).
-            pk.lds_per_wave = (int)((size_t)NT_WM * 16 + (size_t)32 * 32);
-            for (int f0 = 0; f0 < li.nframes; f0 += li.hit_frames) {
-                const int cnt = li.nframes - f0 < li.hit_frames ? li.nframes - f0 : li.hit_frames;
-                NtTarget t2 = tg;
-                t2.dest = tg.dest + (long long)f0 * tg.frame_stride;
-                pk.cams = li.persist_cams + (size_t)f0 * 4 * N;
-                pk.nframes = cnt;
-                pk.hits_out = (float4 *)li.hit_buf;
-                hipLaunchKernelGGL((composite_packet<N, 32, false>), dim3((unsigned)((long long)pk.quads * cnt)), dim3(256),
-                                   (size_t)4 * pk.lds_per_wave, s, sc, t2, pk);
+            pk.lds_per_wave = (int)lds_lean;
+            pk.hits_out = two_pass ? (float4 *)li.hit_buf : nullptr;
+            hipLaunchKernelGGL((composite_packet<N, 32, false>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, t2, pk);
+            if (two_pass) {
                 t2.hits = li.hit_buf;
                 NtCameraFixed c2 = cf;
                 c2.buf = li.persist_cams + (size_t)f0 * 4 * N;
@@ -2728,22 +2775,8 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
                 grid_for(t2, 16, 16, cnt, g2);
                 hipLaunchKernelGGL((composite_kernel<N, true, false>), g2, dim3(256), lds, s, c2, sc, t2);
             }
-            return 0;
         }
-        const dim3 pgrid((unsigned)((long long)pk.quads * li.nframes));
-#define NT_PACKET_CASE(D)                                                                                   \
-    if (sc.stack_depth <= D) {                                                                              \
-        if (feat) {                                                                                         \
-            pk.lds_per_wave = (int)((size_t)64 * ((size_t)N * 8 + (size_t)sc.stack_depth * 4 + NT_MBOX * 4) + NT_WM * 16 + (size_t)D * 32); \
-            hipLaunchKernelGGL((composite_packet<N, D, true>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, tg, pk); \
-        } else {                                                                                            \
-            pk.lds_per_wave = (int)((size_t)NT_WM * 16 + (size_t)D * 32);                                   \
-            hipLaunchKernelGGL((composite_packet<N, D, false>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, tg, pk); \
-        }                                                                                                   \
-        return 0;                                                                                           \
-    }
-        NT_PACKET_CASE(32)        // DEPTH only sizes the per-level LDS records (32 B each)
-#undef NT_PACKET_CASE
+        return 0;
     }
     if (!feat && !sc.stats && !tg.colors_out && li.persist_counter) {
         // persistent waves + ray refill
