@@ -352,11 +352,24 @@ struct Builder {
         if (slices > 1) {
             std::vector<Refs> ls(slices), rs(slices);
             std::vector<std::thread> pool;
-            for (int t = 1; t < slices; ++t)
-                pool.emplace_back([&, t] { classify((int)((long long)m * t / slices), (int)((long long)m * (t + 1) / slices), ls[t], rs[t]); });
-            classify(0, (int)((long long)m / slices), ls[0], rs[0]);
+            std::atomic<bool> failed{false};
+            auto guarded = [&](int t) {
+                try {
+                    classify((int)((long long)m * t / slices), (int)((long long)m * (t + 1) / slices), ls[t], rs[t]);
+                } catch (...) {
+                    failed = true;
+                }
+            };
+            try {
+                for (int t = 1; t < slices; ++t) pool.emplace_back(guarded, t);
+            } catch (...) {
+                failed = true;                                  // could not start every thread
+            }
+            const int started = (int)pool.size() + 1;
+            guarded(0);
             for (auto &th : pool) th.join();
             spare_threads.fetch_add(slices - 1);
+            if (failed || started != slices) throw std::bad_alloc();
             L.begin(n);
             Rr.begin(n);
             for (int t = 0; t < slices; ++t) { L.append(ls[t]); ls[t].release(); Rr.append(rs[t]); rs[t].release(); }
