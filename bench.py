@@ -14,7 +14,8 @@ framebuffer per frame, all 1.3 GB resident in HBM).  K steps are timed between b
 torch.cuda.synchronize() pairs, with HIP events on the launch stream for the kernel time.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): every frame is tiled across the ranks in
-32-row bands (band b -> rank b % N).  Pixels are independent: no collective in the timed region; total
+row bands (band b -> rank b % N; 32 rows = the reference's chunk size, or 16 / 8 rows when that shares the
+rows out more evenly: 1080 rows over 8 ranks are 5-vs-4 bands of 32 rows but 17-vs-16 bands of 8).  Pixels are independent: no collective in the timed region; total
 work is fixed, so scaling is "strong".  The RCCL gather of the finished bands to rank 0 is measured
 separately after the timed region and reported as gather_ms_per_frame / value_incl_gather (like the
 D2H copy at N = 1 it is a delivery step, not part of `value`).
@@ -90,7 +91,10 @@ def main():
     opts.band_world = world
     opts.compact = 1
     opts.strict_reference = 0
-    own_rows = len(ntd.owned_rows(H, rank, world))
+    # band height: the largest of 32 / 16 / 8 rows that leaves the busiest rank the fewest rows
+    band_rows = min((32, 16, 8), key=lambda b: (max(len(ntd.owned_rows(H, r, world, b)) for r in range(world)), -b))
+    opts.band_rows = band_rows
+    own_rows = len(ntd.owned_rows(H, rank, world, band_rows))
     frame_bytes = own_rows * fmt.pitch
     F = max(1, min(args.frames_per_step, nrot))
     fb = torch.empty((F, frame_bytes), dtype=torch.uint8, device="cuda")
@@ -146,7 +150,7 @@ def main():
         reps = 5
         t1 = time.perf_counter()
         for i in range(reps):
-            full = ntd.gather_framebuffer(fb[i % F], fmt, rank, world, dst=0)
+            full = ntd.gather_framebuffer(fb[i % F], fmt, rank, world, dst=0, band_rows=band_rows)
         torch.cuda.synchronize()
         dist.barrier()
         gather_ms = (time.perf_counter() - t1) / reps * 1e3
@@ -196,7 +200,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BoxScene(6) 1920x1080 RGBX8, 160-frame RotatingCamera sequence (configs[2])",
                    "rays_per_step": W * H * F, "frames_per_step": F, "shadow_rays": 0, "launches": launches,
-                   "tiling": "32-row bands round-robin over ranks" if world > 1 else "single GPU",
+                   "tiling": ("%d-row bands round-robin over ranks" % band_rows) if world > 1 else "single GPU",
                    "framebuffer": "resident in HBM (one buffer per frame)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
