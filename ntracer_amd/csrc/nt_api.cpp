@@ -523,6 +523,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             if (int e = ds->numer.ensure(frames * per_frame)) return e;
             li.numer_buf = (float *)ds->numer.p;
             li.numer_frames = (int)frames;
+            if (const char *cf = getenv("NTRACER_CHUNK_FRAMES")) li.numer_frames = std::max(1, std::min(li.numer_frames, atoi(cf)));   // tests
         }
         const bool lit = !s->pl_color.empty() || !s->gl_color.empty() || c.any_reflective;
         const char *e2p = getenv("NTRACER_TWO_PASS");
@@ -533,6 +534,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             if (int e = ds->hits.ensure(frames * per_frame)) return e;
             li.hit_buf = ds->hits.p;
             li.hit_frames = (int)frames;
+            if (const char *cf = getenv("NTRACER_CHUNK_FRAMES")) li.hit_frames = std::max(1, std::min(li.hit_frames, atoi(cf)));
         }
         const char *eto = getenv("NTRACER_TILE_ORDER");
         if (li.persist_cams && !tg.colors_out && !(eto && atoi(eto) == 0)) {

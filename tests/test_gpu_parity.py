@@ -350,6 +350,44 @@ def test_lit_reflective_polytope_packet_vs_tile_vs_oracle(monkeypatch):
     assert frames["0"].view(">f4").max() > 0.5
 
 
+def test_multi_frame_launches_in_chunks(monkeypatch):
+    """Multi-frame launches of composite scenes go through scratch buffers sized in frames (plane numerators; for
+    lit scenes also the primary hits of the two-pass render) and are cut into chunks when those are too small.
+    Forcing one- and two-frame chunks must not change a byte, lit or not."""
+    import torch
+    g = fx.load("cell600_n4")
+    fmt = fmt_of(320, 180, fx.RGBF32)
+    frames = [3, 40, 77, 111, 150]
+    o = np.ascontiguousarray(g["origins"][frames], np.float32)
+    a = np.ascontiguousarray(g["axes"][frames], np.float32)
+    st_ = fmt._as_struct()
+    for lit in (False, True):
+        flat = fx.flat_of(g)
+        sc = tracern.CompositeScene.from_flat(4, flat)
+        if lit:
+            sc.set_params_flat(dict(fov=0.8, shadows=1, camera_light=1, max_reflect_depth=2, bg_gradient_axis=1,
+                                    ambient=[.02, .02, .03], bg1=[1, 1, 1], bg2=[0, 0, 0], bg3=[0, 1, 1],
+                                    point_light_pos=[[20.0, 15.0, -25.0, 5.0]], point_light_color=[[900.0, 800.0, 700.0]],
+                                    global_light_dir=[[0.2, -0.9, 0.3, 0.1]], global_light_color=[[.4, .4, .5]]))
+        out = {}
+        for chunk in ("", "1", "2"):
+            if chunk:
+                monkeypatch.setenv("NTRACER_CHUNK_FRAMES", chunk)
+            else:
+                monkeypatch.delenv("NTRACER_CHUNK_FRAMES", raising=False)
+            fb = torch.zeros((len(frames), fmt.height * fmt.pitch), dtype=torch.uint8, device="cuda")
+            _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), fmt.height * fmt.pitch, len(frames),
+                                                          o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(st_),
+                                                          None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            out[chunk] = fb.cpu().numpy()
+        assert np.array_equal(out[""], out["1"]) and np.array_equal(out[""], out["2"])
+        monkeypatch.delenv("NTRACER_CHUNK_FRAMES", raising=False)
+        sc._set_camera_arrays(g["origins"][77], g["axes"][77])
+        assert np.array_equal(out[""][2].reshape(fmt.height, fmt.pitch), render_host(sc, fmt))
+        assert out[""].view(">f4").max() > 0.3
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
