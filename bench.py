@@ -291,7 +291,7 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
     res["config1_box3_1080p_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
     g = np.load(os.path.join(G, "box_n10_4096x4096.npz"))
     ms = time_scene(tracern.BoxScene(10), ntracer_amd.ImageFormat(4096, 4096, chan), g["origins"], g["axes"], 4, 5)
-    res["config5_box10_4096_var_Mrays_s"] = round(4096 * 4096 / ms / 1e3, 1)
+    res["config5_box10_4096_Mrays_s"] = round(4096 * 4096 / ms / 1e3, 1)
     g = np.load(os.path.join(G, "cell120_n4.npz"))
     sc = tracern.CompositeScene.from_flat(4, g)
     sel = [0, 20, 40, 60, 80, 100, 120, 140]

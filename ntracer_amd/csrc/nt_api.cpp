@@ -374,6 +374,7 @@ void fill_composite(const nt_scene *s, const DeviceState *ds, NtCompositeDev &c,
     c.any_reflective = s->any_reflective;
     c.has_scalar_prims = s->has_scalar;
     c.n_batches = s->n_batches;
+    c.n_solids = s->n_solids;
     c.stats = stats ? (unsigned long long *)ds->stats.p : nullptr;
 }
 

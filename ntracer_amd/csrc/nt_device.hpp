@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 #define NT_DEV_MAX_DIM 64
-#define NT_DEV_MAX_FIXED 8
+#define NT_DEV_MAX_FIXED 10
 #define NT_DEV_BATCH 4
 #define NT_DEV_MAX_REFLECT 16
 
@@ -104,7 +104,7 @@ struct NtCompositeDev {
     int all_opaque;           // every material has opacity >= 1
     int any_reflective;
     int has_scalar_prims;     // leaves hold unbatched triangles or solids
-    int n_batches;
+    int n_batches, n_solids;
     int prune;                // 1: closest-hit walks drop subtrees that start clearly beyond the current hit (nt_beyond_hit)
     unsigned long long *stats;  // nullptr or 8 counters (nt_stats order)
 };

@@ -2816,14 +2816,23 @@ int finish_launch(const char *what) {
 
 const char *nt_launch_error() { return g_launch_error; }
 
+// NTRACER_FORCE_VAR=1: use the run-time-n kernels for every dimension (they are the only ones above
+// NT_DEV_MAX_FIXED; the switch lets tests compare them with the compile-time-N kernels on the same scene)
+static bool force_var() {
+    const char *e = getenv("NTRACER_FORCE_VAR");
+    return e && atoi(e) != 0;
+}
+
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg) {
-    switch (li.n) {
+    switch (force_var() ? 0 : li.n) {
         case 3: launch_box_fixed<3>(li, cam, tg); break;
         case 4: launch_box_fixed<4>(li, cam, tg); break;
         case 5: launch_box_fixed<5>(li, cam, tg); break;
         case 6: launch_box_fixed<6>(li, cam, tg); break;
         case 7: launch_box_fixed<7>(li, cam, tg); break;
         case 8: launch_box_fixed<8>(li, cam, tg); break;
+        case 9: launch_box_fixed<9>(li, cam, tg); break;
+        case 10: launch_box_fixed<10>(li, cam, tg); break;
         default: {
             dim3 grid;
             grid_for(tg, 64, 4, li.nframes, grid);
@@ -2836,16 +2845,22 @@ int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &t
 
 int nt_launch_composite(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg) {
     int r;
-    switch (li.n) {
+    switch (force_var() ? 0 : li.n) {
         case 3: r = launch_composite_fixed<3>(li, cam, sc, tg); break;
         case 4: r = launch_composite_fixed<4>(li, cam, sc, tg); break;
         case 5: r = launch_composite_fixed<5>(li, cam, sc, tg); break;
         case 6: r = launch_composite_fixed<6>(li, cam, sc, tg); break;
         case 7: r = launch_composite_fixed<7>(li, cam, sc, tg); break;
         case 8: r = launch_composite_fixed<8>(li, cam, sc, tg); break;
+        case 9: r = launch_composite_fixed<9>(li, cam, sc, tg); break;
+        case 10: r = launch_composite_fixed<10>(li, cam, sc, tg); break;
         default: {
             if (li.n < 3 || li.n > NT_DEV_MAX_DIM) {
                 snprintf(g_launch_error, sizeof(g_launch_error), "unsupported dimension %d", li.n);
+                return -2;
+            }
+            if (sc.n_point_lights || sc.n_global_lights || sc.any_reflective || sc.n_solids || !sc.all_opaque) {
+                snprintf(g_launch_error, sizeof(g_launch_error), "the run-time-n kernel renders opaque, non-reflective simplices lit by the camera light only");
                 return -2;
             }
             // run-time-n kernel: one wave per 8x8 tile (probe mode: 64 probes per block)

@@ -83,10 +83,11 @@ def test_box_full_frame_bytes_equal_oracle(n, w, h):
         assert np.array_equal(img, ref)
 
 
-def test_box10_4096_var_kernel_properties_and_samples():
-    """config 5 at full size: run-time-n kernel, 4096x4096.  Oracle on sampled rows; at full size the
-    frame must be invariant under the band decomposition (2 ranks, compact) and identical between the
-    host path and the device path."""
+def test_box10_4096_both_kernels_properties_and_samples(monkeypatch):
+    """config 5 at full size, 4096x4096, through the compile-time-N kernel (default for n <= 10) and through the
+    run-time-n kernel (NTRACER_FORCE_VAR; the only one for n > 10): identical frames.  Oracle on sampled rows; at
+    full size the frame must be invariant under the band decomposition (2 ranks, compact) and identical between
+    the host path and the device path."""
     import torch
     g = fx.load("box_n10_4096x4096")
     w = h = 4096
@@ -94,6 +95,9 @@ def test_box10_4096_var_kernel_properties_and_samples():
     sc._set_camera_arrays(g["origins"][40], g["axes"][40])
     fmt = fmt_of(w, h, fx.RGBX8)
     img = render_host(sc, fmt)
+    monkeypatch.setenv("NTRACER_FORCE_VAR", "1")
+    assert np.array_equal(render_host(sc, fmt), img)
+    monkeypatch.delenv("NTRACER_FORCE_VAR")
     osc = ob.OracleScene(10, g["origins"][40], g["axes"][40])
     for y in (0, 1777, 2048, 4095):
         xs = np.arange(w)
@@ -184,6 +188,21 @@ def test_ragged_and_tiny_images():
 
 
 # ------------------------------------------------------------------ CompositeScene (config 4)
+def test_simplex10_fixed_and_run_time_n_kernels_agree(monkeypatch):
+    """A 10-D composite scene renders through launch_composite_fixed<10> by default and through
+    composite_kernel_var when forced: same colours (both mirror the oracle's operation order)."""
+    g = fx.load("simplex10_n10")
+    sc = tracern.CompositeScene.from_flat(10, fx.flat_of(g))
+    f = g["frames"][2]
+    sc._set_camera_arrays(g["origins"][f], g["axes"][f])
+    fmt = fmt_of(320, 200, fx.RGBF32)
+    a = render_host(sc, fmt)
+    monkeypatch.setenv("NTRACER_FORCE_VAR", "1")
+    b = render_host(sc, fmt)
+    assert np.abs(a.view(">f4") - b.view(">f4")).max() < 1e-6
+    assert a.view(">f4").max() > 0.2
+
+
 @pytest.mark.parametrize("name", ["cell600_n4", "cell120_n4", "orthoplex5_n5", "simplex10_n10"])
 def test_polytope_vs_oracle_and_reference(name):
     g = fx.load(name)
