@@ -203,6 +203,31 @@ def test_simplex10_fixed_and_run_time_n_kernels_agree(monkeypatch):
     assert a.view(">f4").max() > 0.2
 
 
+def test_lit_reflective_scene_in_ten_dimensions_vs_oracle():
+    """n = 9 and 10 go through the compile-time-N kernels, i.e. with the full feature set (the reference's generic
+    module has it for any n): lights, shadows and reflection on the 10-D simplex against the oracle."""
+    g = fx.load("simplex10_n10")
+    flat = fx.flat_of(g)
+    m = np.array(flat["materials"], np.float32).copy()
+    m[:, 7] = 0.25
+    flat["materials"] = m
+    n = 10
+    params = dict(fov=0.8, shadows=1, camera_light=1, max_reflect_depth=2, bg_gradient_axis=1,
+                  ambient=[.02, .02, .03], bg1=[1, 1, 1], bg2=[0, 0, 0], bg3=[0, 1, 1],
+                  point_light_pos=[[6.0, 5.0, -7.0, 2.0, 1.0, -1.0, 0.5, 0.0, 2.0, -3.0]], point_light_color=[[9e8, 8e8, 7e8]],
+                  global_light_dir=[[0.2, -0.9, 0.3, 0.1, 0.0, 0.1, -0.1, 0.0, 0.05, 0.0]], global_light_color=[[.4, .4, .5]])
+    sc = tracern.CompositeScene.from_flat(n, flat)
+    sc.set_params_flat(params)
+    f = g["frames"][1]
+    sc._set_camera_arrays(g["origins"][f], g["axes"][f])
+    fmt = fmt_of(160, 100, fx.RGBF32)
+    img = render_host(sc, fmt)
+    ref = ob.OracleScene(n, g["origins"][f], g["axes"][f], flat=flat, params=params, clean_normals=True).render(160, 100, fx.RGBF32, threads=7)
+    d = np.abs(img.view(">f4") - ref.view(">f4"))
+    assert d.max() < 1e-4, float(d.max())
+    assert img.view(">f4").max() > 0.3
+
+
 @pytest.mark.parametrize("name", ["cell600_n4", "cell120_n4", "orthoplex5_n5", "simplex10_n10"])
 def test_polytope_vs_oracle_and_reference(name):
     g = fx.load(name)
