@@ -248,9 +248,7 @@ def build_scene(schlafli, material=None, cam_dist=4.0, nt=None):
     if is_hypercube(comps):
         return nt, nt.BoxScene(), -math.sqrt(n) * cam_dist
     p = RegularPolytope(comps)
-    hull = p.hull(nt, material or Material((1, 0.5, 0.5)))
-    # big meshes (subdivided star polytopes): a branch step must buy more before the builder takes it
-    scene = nt.build_composite_scene(hull, traversal_cost=4.0 if len(hull) > 20000 else 0.0)
+    scene = nt.build_composite_scene(p.hull(nt, material or Material((1, 0.5, 0.5))))
     return nt, scene, -math.sqrt(p.circumradius_square()) * cam_dist
 
 
