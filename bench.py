@@ -309,6 +309,16 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
     bytes_pruned = 16 * 31.2 + 8 * 4.46 + 168 * (4 + 4 * 21) + 4
     res["config4_default_walk_bytes_per_ray"] = round(bytes_pruned)
     res["config4_default_walk_TB_s"] = round(bytes_pruned * 1920 * 1080 / (ms * 1e-3) / 1e12, 2)
+    # the reference's own simplices and batches under OUR k-d tree (nt_kdtree_build): identical pixels, fewer tests
+    try:
+        t0 = time.perf_counter()
+        reb = sc.with_rebuilt_tree()
+        reb_s = time.perf_counter() - t0
+        ms_reb = time_scene(reb, ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"][sel], g["axes"][sel], 8, 2)
+        res["config4_rebuilt_tree"] = {"ms_per_frame": round(ms_reb, 3), "Mrays_s": round(1920 * 1080 / ms_reb / 1e3, 1),
+                                       "build_s": round(reb_s, 1), "nodes": int(len(reb._flat["node_axis"]))}
+    except Exception as e:
+        res["config4_rebuilt_tree"] = {"error": str(e)[:200]}
     # the same polytope generated and partitioned on our side (ntracer_amd.polytope + nt_kdtree_build) -- SURVEY 8d's
     # "build-tree figure"; pixels equal the reference-built scene's except on silhouettes (the reference inflates facets)
     try:

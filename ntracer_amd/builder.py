@@ -122,6 +122,23 @@ def vertices_of(p1, face_normal, edge_normals):
     return np.vstack([p1, p1 + sk.T]).astype(f32)
 
 
+def vertices_of_many(recs, n):
+    """vertices_of for an array of records (count, >= 1+n+n+(n-1)*n) in the device layout
+    [d, face_normal[n], p1[n], edge_normals[n-1][n]] -> (count, n, n) float64."""
+    r = np.asarray(recs, np.float64)
+    fn = r[:, 1:1 + n]
+    p1 = r[:, 1 + n:1 + 2 * n]
+    en = r[:, 1 + 2 * n:1 + 2 * n + (n - 1) * n].reshape(-1, n - 1, n)
+    m = np.concatenate([en, fn[:, None, :]], axis=1)                     # rows: E_0..E_{n-2}, N
+    rhs = np.zeros((len(r), n, n - 1))
+    rhs[:, :n - 1, :] = -np.eye(n - 1)
+    sk = np.linalg.solve(m, rhs)                                         # columns: edge vectors
+    out = np.empty((len(r), n, n))
+    out[:, 0, :] = p1
+    out[:, 1:, :] = p1[:, None, :] + np.swapaxes(sk, 1, 2)
+    return out
+
+
 def solid_bounds(type_cube, position, orientation):
     """World-space bounding box of a Solid: x = orientation * (u + position), u in [-1,1]^n (cube) or
     |u| <= 1 (sphere) -- solid::intersects (tracer.hpp:257-260) read backwards."""

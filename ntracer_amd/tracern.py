@@ -639,6 +639,58 @@ class CompositeScene(_SceneBase):
                     materials=np.asarray(mats, f32).reshape(-1, 10),
                     aabb_start=boundary.start._v, aabb_end=boundary.end._v)
 
+    def with_rebuilt_tree(self, **kwds):
+        """A new CompositeScene over the SAME primitive tables (batches, triangles, solids, materials -- so the same
+        pixels: nearest hits do not depend on the tree) with the k-d tree rebuilt by the native builder.  Keyword
+        arguments as for build_kdtree (max_depth, split_threshold, traversal_cost, intersection_cost).  Scene
+        parameters (lights, background, fov, camera) are copied.  With shadows on the pixels DO depend on the tree,
+        here as in the reference: its occlusion walk skips the far child of a branch whenever the split lies nearer
+        than the light (tracer.hpp:1298), so a different tree finds different blockers."""
+        f = self._flat
+        n = self.dimension
+        items = []
+        brec = np.asarray(f["batch_recs"], np.float64).reshape(-1, BATCH_SIZE, n * n + n + 1)
+        if len(brec):
+            bv = builder.vertices_of_many(brec.reshape(-1, brec.shape[2]), n).reshape(len(brec), BATCH_SIZE, n, n)
+            for k in range(len(brec)):
+                items.append(builder._Item((k << 2) | _lib.KIND_BATCH, bv[k].min(axis=(0, 1)), bv[k].max(axis=(0, 1)), bv[k]))
+        trec = np.asarray(f["tri_recs"], np.float64).reshape(-1, n * n + n + 1)
+        if len(trec):
+            tv = builder.vertices_of_many(trec, n)
+            for k in range(len(trec)):
+                items.append(builder._Item((k << 2) | _lib.KIND_TRIANGLE, tv[k].min(axis=0), tv[k].max(axis=0), tv[k][None]))
+        srec = np.asarray(f["solid_recs"], np.float64).reshape(-1, 2 * n * n + n)
+        for k in range(len(srec)):
+            lo, hi = builder.solid_bounds(int(f["solid_types"][k]) == CUBE, srec[k, 2 * n * n:], srec[k, :n * n].reshape(n, n))
+            items.append(builder._Item((k << 2) | _lib.KIND_SOLID, lo, hi))
+        nodes, leaf_items = [], []
+
+        def leaf(prims):
+            nodes.append([-1, 0.0, len(leaf_items), len(prims)])
+            leaf_items.extend(prims)
+            return len(nodes) - 1
+
+        def branch(axis, split, left, right):
+            nodes.append([axis, split, -1 if left is None else left, -1 if right is None else right])
+            return len(nodes) - 1
+
+        lo, hi, root = builder.build_tree(items, leaf, branch, int(kwds.pop("max_depth", builder.KD_DEFAULT_MAX_DEPTH)),
+                                          int(kwds.pop("split_threshold", builder.KD_DEFAULT_SPLIT_THRESHOLD)),
+                                          float(kwds.pop("traversal_cost", 0.0)), float(kwds.pop("intersection_cost", 0.0)))
+        if kwds:
+            raise TypeError("unexpected keyword argument %r" % next(iter(kwds)))
+        nd = np.asarray(nodes, np.float64).reshape(-1, 4)
+        d = {k: np.array(v) for k, v in f.items()}
+        d.update(root=root, node_axis=nd[:, 0].astype(np.int32), node_split=nd[:, 1].astype(f32),
+                 node_left=nd[:, 2].astype(np.int32), node_right=nd[:, 3].astype(np.int32),
+                 items=np.asarray(leaf_items, np.int32), aabb_start=lo, aabb_end=hi)
+        other = CompositeScene.from_flat(n, d)
+        other.set_fov(self.fov)
+        other._push(_pl=list(self._point_lights), _gl=list(self._global_lights), **dict(self._p))
+        cam = self.get_camera()
+        other._set_camera_arrays(cam._origin, cam._axes)
+        return other
+
     def _flat_description(self):
         """The flat arrays this scene was created from (layout of nt_scene_desc / tests/golden/*.npz)."""
         return {k: np.array(v) for k, v in self._flat.items()}

@@ -432,6 +432,27 @@ def test_multi_frame_launches_in_chunks(monkeypatch):
         assert out[""].view(">f4").max() > 0.3
 
 
+def test_rebuilt_tree_renders_the_same_bytes():
+    """CompositeScene.with_rebuilt_tree keeps the primitive tables and replaces the k-d tree by one from the native
+    builder: nearest hits do not depend on the tree, so full frames come out the same -- on the reference-built
+    600-cell and 120-cell, default and strict walks -- except where a ray meets the shared edge of two simplices at
+    exactly the same distance: the first one tested wins (tracer.hpp:585, strict <), and the order is the tree's."""
+    for name, frames in (("cell600_n4", (5, 77)), ("cell120_n4", (40,))):
+        g = fx.load(name)
+        sc = tracern.CompositeScene.from_flat(4, fx.flat_of(g))
+        reb = sc.with_rebuilt_tree()
+        assert len(reb._flat["batch_recs"]) == len(sc._flat["batch_recs"])
+        fmt = fmt_of(1920, 1080, fx.RGBX8)
+        for f in frames:
+            sc._set_camera_arrays(g["origins"][f], g["axes"][f])
+            reb._set_camera_arrays(g["origins"][f], g["axes"][f])
+            a = render_host(sc, fmt).reshape(1080, 1920, 4)
+            b = render_host(reb, fmt).reshape(1080, 1920, 4)
+            ties = (a != b).any(axis=2).sum()
+            assert ties <= 2e-4 * 1920 * 1080, (name, f, int(ties))
+            assert np.array_equal(b, render_host(reb, fmt, strict_reference=True).reshape(1080, 1920, 4)), (name, f)
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
