@@ -161,12 +161,14 @@ class _Item(object):
 
 
 def group_batches(tri_items, batch_size, make_batch):
-    """Pack triangles into batches of `batch_size` spatial neighbours; leftovers stay unbatched.  (The reference
+    """Pack triangles into batches of `batch_size` spatial neighbours; leftovers form a padded batch.  (The reference
     sorts by centre along the widest axis and packs greedily by a distance metric, tracer.hpp:2395-2427; here the
     centres are split recursively at the median of their widest axis until groups of `batch_size` remain, which
     keeps each batch's bounding box small in every axis.)"""
+    if not tri_items:
+        return [], []
     if len(tri_items) < batch_size:
-        return [], list(tri_items)
+        return [_pad_batch(list(tri_items), batch_size, make_batch)], []
     centres = np.asarray([(it.lo + it.hi) * 0.5 for it in tri_items])
     groups = []
 
@@ -197,7 +199,22 @@ def group_batches(tri_items, batch_size, make_batch):
             batches.append(_Item(make_batch([g.prim for g in members]), lo, hi, simp))
         else:
             loose.extend(tri_items[i] for i in grp)
+    if loose:
+        # the leftovers (fewer than a batch) become one more batch, its last triangle repeated: a duplicate lane can
+        # never win (strict <), and a scene made of batches only is eligible for the packet kernel.  (The reference
+        # leaves them as single triangles, tracer.hpp:2395-2427.)
+        batches.append(_pad_batch(loose, batch_size, make_batch))
+        loose = []
     return batches, loose
+
+
+def _pad_batch(members, batch_size, make_batch):
+    lo = np.min([g.lo for g in members], axis=0)
+    hi = np.max([g.hi for g in members], axis=0)
+    simp = np.concatenate([g.simplices for g in members]) if all(g.simplices is not None for g in members) else None
+    prims = [g.prim for g in members]
+    prims += [prims[-1]] * (batch_size - len(prims))
+    return _Item(make_batch(prims), lo, hi, simp)
 
 
 def build_tree(items, make_leaf, make_branch, max_depth=KD_DEFAULT_MAX_DEPTH, split_threshold=KD_DEFAULT_SPLIT_THRESHOLD,

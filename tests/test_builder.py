@@ -149,8 +149,8 @@ def test_kdtree_build_abi():
                              tris.ctypes.data_as(_lib.f32p), None, None) == _lib.NT_E_INVALID
 
 
-def test_tree_independence_with_solids_and_loose_triangles():
-    """A mixed 3-D scene (solids, 6 loose triangles + batches): the built tree must give the same colours as a
+def test_tree_independence_with_solids_and_a_padded_batch():
+    """A mixed 3-D scene (solids, 22 triangles = 5 batches + a padded one): the built tree must give the same colours as a
     single leaf holding everything (brute force)."""
     rnd = np.random.RandomState(5)
     nt = NTracer(3)
@@ -164,7 +164,7 @@ def test_tree_independence_with_solids_and_loose_triangles():
     protos.append(nt.SolidPrototype(ntracer_amd.SPHERE, nt.Vector(-1.2, .2, .6), nt.Matrix.scale(.8), mats[1]))
     boundary, root = tracern.build_kdtree(protos)
     flat = _flat_of_scene(boundary, root)
-    assert len(flat["batch_recs"]) == 5 and len(flat["tri_recs"]) == 2 and len(flat["solid_recs"]) == 2
+    assert len(flat["batch_recs"]) == 6 and len(flat["tri_recs"]) == 0 and len(flat["solid_recs"]) == 2      # 22 triangles: 5 batches + a padded one
     # brute force: one leaf with every primitive
     every = []
 

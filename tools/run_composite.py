@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Render the 120-cell (config 4) a few times -- target for rocprofv3 runs."""
+"""Render the 120-cell (config 4) a few times -- target for rocprofv3 runs.
+usage: run_composite.py [fixture [frames [rebuilt]]]   ("rebuilt": the same primitives under our own k-d tree)"""
 import ctypes as C
 import os
 import sys
@@ -17,6 +18,8 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
 n = int(g["dimension"])
 sc = tracern.CompositeScene.from_flat(n, g)
+if len(sys.argv) > 3 and sys.argv[3] == "rebuilt":
+    sc = sc.with_rebuilt_tree()
 W, H = 1920, 1080
 fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(8, 1, 0, 0), ntracer_amd.Channel(8, 0, 1, 0),
                                      ntracer_amd.Channel(8, 0, 0, 1), ntracer_amd.Channel(8, 0, 0, 0)])
