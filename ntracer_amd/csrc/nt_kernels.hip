@@ -852,7 +852,7 @@ __device__ __forceinline__ float branch_t(const WaveLds &w, int lane, const NtNo
 }
 
 template <int N, bool FEAT, bool STATS>
-__device__ __forceinline__ bool trace_closest(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
+__device__ __noinline__ bool trace_closest(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
                                               float t_near, float t_far_root, int skip_item, int skip_lane, Hit &hit, Stats &st) {
     hit.dist = FLT_MAX;
     hit.item = -1;
