@@ -504,7 +504,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         if (c.root < 0) c.root = -1;
         // image renders of opaque scenes made of batches go through the packet kernel (primary rays share the
         // camera origin): it needs the camera table in device memory (and, for the persistent variant, a counter)
-        const bool packetable = c.all_opaque && !c.has_scalar_prims;
+        const bool packetable = c.all_opaque != 0;
         if (packetable && !job.stats && !job.colors_out && s->n <= NT_MAX_FIXED_DIM && li.kernel_choice != 2) {
             // persistent kernel: a zeroed work counter and the camera table in device memory (stream ordered)
             if (int e = ds->counter.ensure(8)) return e;
@@ -528,7 +528,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             li.numer_frames = (int)frames;
             if (const char *cf = getenv("NTRACER_CHUNK_FRAMES")) li.numer_frames = std::max(1, std::min(li.numer_frames, atoi(cf)));   // tests
         }
-        const bool lit = !s->pl_color.empty() || !s->gl_color.empty() || c.any_reflective;
+        const bool lit = !s->pl_color.empty() || !s->gl_color.empty() || c.any_reflective || c.has_scalar_prims;
         const char *e2p = getenv("NTRACER_TWO_PASS");
         if (li.persist_cams && !tg.colors_out && lit && !(e2p && atoi(e2p) == 0)) {
             // scratch for the primary hits of a two-pass render: as many frames as fit in 512 MB, at least one

@@ -2399,8 +2399,8 @@ __device__ __forceinline__ bool wm_claim(int *wm, int lane, int item, bool activ
 // neighbouring rays walk the same leaves, so the four waves share what their scalar loads bring into the CU's
 // scalar cache (blocks of unrelated tiles ran ~12 % slower).  Quads are dispatched through a host table: quad
 // rows nearest the image centre first (they hold the long walks), row-major within a row.
-template <int N, int DEPTH, bool FEAT>
-__global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtCompositeDev sc, NtTarget tg, PacketArgs pa) {
+template <int N, int DEPTH, bool FEAT, bool SCAL>
+__global__ __launch_bounds__(256, FEAT ? 1 : ((N <= 4 && !SCAL) ? 6 : (N <= 7 ? 5 : 4))) void composite_packet(NtCompositeDev sc, NtTarget tg, PacketArgs pa) {
     extern __shared__ float2 lds_raw[];
     const int lane = (int)threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -2480,6 +2480,25 @@ __global__ __launch_bounds__(256, FEAT ? 1 : 6) void composite_packet(NtComposit
                     if (__builtin_amdgcn_ballot_w64(cur_doit) == 0ull) {
                         doit = false;
                         if (more) doit = wm_claim(wm, lane, item, active);
+                        continue;
+                    }
+                    if (SCAL && (cur & 3) != 0) {
+                        // an unbatched triangle or a solid (they follow the batches in every leaf, tracer.hpp:994,1149):
+                        // the per-lane tests of leaf_closest, on a record every lane reads from the same address
+                        doit = false;
+                        if (more) doit = wm_claim(wm, lane, item, active);
+                        if (cur_doit) {
+                            float t;
+                            if ((cur & 3) == 1) {
+                                SimplexRec<N> sr;
+                                sr.load(sc.tri_recs + (size_t)(cur >> 2) * sc.rec_stride);
+                                t = simplex_scalar_form<N>(sr, o, d, hit.dist);
+                            } else {
+                                float no_[N], nd_[N];
+                                t = solid_intersects<N>(sc, cur >> 2, o, d, hit.dist, false, no_, nd_);
+                            }
+                            if (t != 0.0f) { hit.dist = t; hit.item = cur; hit.lane = -1; improved = true; }
+                        }
                         continue;
                     }
                     const float *base = sc.batch_recs + (size_t)(cur >> 2) * NT_DEV_BATCH * sc.rec_stride;
@@ -2720,7 +2739,10 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
         hipLaunchKernelGGL((composite_kernel_t<N>), grid, dim3(256), lds, s, cf, sc, tg);
         return 0;
     }
-    if (!sc.has_scalar_prims && !sc.stats && !tg.colors_out && li.persist_cams && li.kernel_choice == 0 && sc.stack_depth <= 32) {
+    // scenes with unbatched triangles or solids take the packet walk only as the first of two passes (their hits
+    // are shaded by the general kernel)
+    const bool two_pass_ok = feat && li.hit_buf && li.hit_frames > 0;
+    if ((!sc.has_scalar_prims || two_pass_ok) && !sc.stats && !tg.colors_out && li.persist_cams && li.kernel_choice == 0 && sc.stack_depth <= 32) {
         // packet kernel: one wave per 8x8 tile, wave-uniform tree walk for the primary rays
         PacketArgs pk;
         pk.cams = li.persist_cams;
@@ -2758,7 +2780,7 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
             const dim3 pgrid((unsigned)((long long)pk.quads * cnt));
             if (single_feat) {
                 pk.lds_per_wave = (int)lds_feat;
-                hipLaunchKernelGGL((composite_packet<N, 32, true>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, t2, pk);
+                hipLaunchKernelGGL((composite_packet<N, 32, true, false>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, t2, pk);
                 continue;
             }
             // Lit scenes in two passes: the lean packet kernel (47 VGPRs, 6 waves/SIMD) finds the primary hits, then
@@ -2766,7 +2788,10 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
             // kernel doing both ran its primary walk at the shading code's occupancy (1 wave/SIMD).
             pk.lds_per_wave = (int)lds_lean;
             pk.hits_out = two_pass ? (float4 *)li.hit_buf : nullptr;
-            hipLaunchKernelGGL((composite_packet<N, 32, false>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, t2, pk);
+            if (sc.has_scalar_prims)
+                hipLaunchKernelGGL((composite_packet<N, 32, false, true>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, t2, pk);
+            else
+                hipLaunchKernelGGL((composite_packet<N, 32, false, false>), pgrid, dim3(256), (size_t)4 * pk.lds_per_wave, s, sc, t2, pk);
             if (two_pass) {
                 t2.hits = li.hit_buf;
                 NtCameraFixed c2 = cf;

@@ -453,6 +453,40 @@ def test_rebuilt_tree_renders_the_same_bytes():
             assert np.array_equal(b, render_host(reb, fmt, strict_reference=True).reshape(1080, 1920, 4)), (name, f)
 
 
+def test_scenes_with_solids_and_loose_triangles_take_the_packet_walk(monkeypatch):
+    """Image renders of opaque scenes whose leaves hold unbatched triangles and solids go through the packet
+    kernel for the primary hits (per-lane tests on uniformly addressed records) and the general kernel for the
+    shading.  Same bytes as the all-per-lane tile kernel, and the oracle's colours, on every variant of the feature
+    scene (lights, shadows, reflection) and on the 10-D simplex (2 batches + 3 loose triangles)."""
+    g = fx.load("feature3d")
+    flat = fx.flat_of(g, opaque=True)
+    w, h = int(g["width"]), int(g["height"])
+    fmt = fmt_of(w, h, fx.RGBF32)
+    for v in g["variants"]:
+        p = fx.params_of(g, "%s__" % v)
+        frames = {}
+        for choice in ("0", "2"):
+            monkeypatch.setenv("NTRACER_COMPOSITE_KERNEL", choice)
+            sc = tracern.CompositeScene.from_flat(3, flat)
+            sc.set_params_flat(p)
+            sc._set_camera_arrays(g["origin"], g["axes"])
+            frames[choice] = render_host(sc, fmt)
+        assert np.array_equal(frames["0"], frames["2"]), str(v)
+        ref = ob.OracleScene(3, g["origin"], g["axes"], flat=flat, params=p, clean_normals=True).render(w, h, fx.RGBF32, threads=7)
+        assert np.abs(frames["0"].view(">f4") - ref.view(">f4")).max() < TOL_ORACLE, str(v)
+    g = fx.load("simplex10_n10")
+    flat = fx.flat_of(g)
+    assert len(flat["tri_recs"]) == 3
+    fmt = fmt_of(200, 120, fx.RGBF32)
+    frames = {}
+    for choice in ("0", "2"):
+        monkeypatch.setenv("NTRACER_COMPOSITE_KERNEL", choice)
+        sc = tracern.CompositeScene.from_flat(10, flat)
+        sc._set_camera_arrays(g["origins"][9], g["axes"][9])
+        frames[choice] = render_host(sc, fmt)
+    assert np.array_equal(frames["0"], frames["2"])
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
