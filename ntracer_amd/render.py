@@ -404,7 +404,8 @@ class BlockingRenderer(object):
         self._mut = threading.Lock()
         self._busy = False
 
-    def render(self, dest, format, scene, band_rank=0, band_world=1, compact=False, collect_stats=False, strict_reference=None):
+    def render(self, dest, format, scene, band_rank=0, band_world=1, compact=False, collect_stats=False, strict_reference=None,
+               band_rows=0):
         if not isinstance(format, ImageFormat):
             raise TypeError("format must be an ImageFormat")
         if not isinstance(scene, Scene):
@@ -420,12 +421,12 @@ class BlockingRenderer(object):
             L = _lib.lib()
             if dev is not None:
                 ptr, nbytes, index, stream = dev
-                opts = _opts(index, band_rank, band_world, compact, collect_stats, strict_reference=strict_reference)
+                opts = _opts(index, band_rank, band_world, compact, collect_stats, band_rows=band_rows, strict_reference=strict_reference)
                 _lib.check(L.nt_render_device(scene._handle, C.c_void_p(ptr), nbytes, C.byref(fmt), C.byref(opts),
                                               C.c_void_p(stream)))
                 return True
             arr, n = _host_buffer(dest)
-            opts = _opts(self.device, band_rank, band_world, compact, collect_stats, strict_reference=strict_reference)
+            opts = _opts(self.device, band_rank, band_world, compact, collect_stats, band_rows=band_rows, strict_reference=strict_reference)
             r = _lib.check(L.nt_render(scene._handle, arr, n, C.byref(fmt), C.byref(opts), C.byref(self._abort)))
             return r != _lib.NT_ABORTED
         finally:

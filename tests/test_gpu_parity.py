@@ -487,6 +487,27 @@ def test_scenes_with_solids_and_loose_triangles_take_the_packet_walk(monkeypatch
     assert np.array_equal(frames["0"], frames["2"])
 
 
+@pytest.mark.parametrize("band_rows,world", [(8, 8), (16, 4), (8, 3)])
+def test_band_heights_other_than_32(band_rows, world):
+    """nt_render_opts.band_rows: the ranks' compact buffers, de-interleaved with the same band height, give the
+    whole frame -- BoxScene (64x4-pixel blocks) and a composite scene (16x16-pixel quads of the packet kernel)."""
+    g = fx.load("cell600_n4")
+    scenes = [tracern.BoxScene(6), tracern.CompositeScene.from_flat(4, fx.flat_of(g))]
+    gb = fx.load("box_n6_1920x1080")
+    scenes[0]._set_camera_arrays(gb["origins"][21], gb["axes"][21])
+    scenes[1]._set_camera_arrays(g["origins"][33], g["axes"][33])
+    fmt = fmt_of(500, 301, fx.RGBX8)
+    for sc in scenes:
+        whole = render_host(sc, fmt)
+        re = np.zeros_like(whole)
+        for r in range(world):
+            rows = ntd.owned_rows(fmt.height, r, world, band_rows)
+            buf = bytearray(len(rows) * fmt.pitch)
+            assert ntracer_amd.BlockingRenderer().render(buf, fmt, sc, band_rank=r, band_world=world, compact=True, band_rows=band_rows)
+            re[rows] = np.frombuffer(bytes(buf), np.uint8).reshape(len(rows), fmt.pitch)
+        assert np.array_equal(re, whole)
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
