@@ -249,6 +249,16 @@ int nt_kdtree_build(int dimension, int n_items, const float *item_lo, const floa
                     const float *simplex_verts, const nt_kdtree_params *params, nt_kdtree *out);
 void nt_kdtree_free(nt_kdtree *t);
 
+/* aabb::intersects(prototype) of the reference (src/tracer.hpp:1465-1700), done by exact clipping: a convex polytope
+   -- `n_verts` vertices [n_verts][dimension], each with the set of its facets' ids as a 192-bit mask `tight`
+   [n_verts][3]; two vertices span an edge when they share `shared_for_edge` facets -- is cut by the 2*dimension
+   half-spaces of the box [lo, hi] (which get the facet ids first_free_bit ...).  Returns the number of vertices of
+   what is left (0: disjoint; out_lo / out_hi then untouched, else its bounding box), or a negative status.
+   dimension <= 16.  A simplex: vertex i is on every facet but i, shared_for_edge = dimension-2; a parallelotope
+   (solid cube): vertex on one facet of each of the dimension pairs, shared_for_edge = dimension-1. */
+int nt_polytope_clip_box(int dimension, int n_verts, const float *verts, const uint64_t *tight, int shared_for_edge, int first_free_bit,
+                         const float *lo, const float *hi, float *out_lo, float *out_hi);
+
 #ifdef __cplusplus
 }
 #endif

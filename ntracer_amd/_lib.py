@@ -119,6 +119,7 @@ SYMBOLS = [
     ("nt_scene_last_stats", C.c_int, [C.c_void_p, C.POINTER(NtStats)]),
     ("nt_kdtree_build", C.c_int, [C.c_int, C.c_int, f32p, f32p, i32p, f32p, C.POINTER(NtKdTreeParams), C.POINTER(NtKdTree)]),
     ("nt_kdtree_free", None, [C.POINTER(NtKdTree)]),
+    ("nt_polytope_clip_box", C.c_int, [C.c_int, C.c_int, f32p, C.POINTER(C.c_uint64), C.c_int, C.c_int, f32p, f32p, f32p, f32p]),
 ]
 
 _lib = None

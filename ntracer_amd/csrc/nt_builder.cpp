@@ -104,8 +104,11 @@ struct Builder {
     // Cut the polytope (nv vertices at x/t) with the half-space sgn*(x_a - bound) >= 0, append what is left to `dst`
     // as a new slot.  Returns false if the result outgrew NT_CLIP_MAX_VERTS (nothing appended).
     bool cut(const double *x, const uint64_t *t, int nv, int a, double sgn, double bound, int cbit, Refs &dst) const {
+        return cut_general(x, t, nv, a, sgn, bound, cbit, n - 2, dst);   // an edge of an (n-1)-polytope: n-2 shared tight constraints
+    }
+
+    bool cut_general(const double *x, const uint64_t *t, int nv, int a, double sgn, double bound, int cbit, int need, Refs &dst) const {
         const double eps = 1e-10 * scale;
-        const int need = n - 2;              // an edge of an (n-1)-polytope: n-2 shared tight constraints
         static thread_local std::vector<double> dist;
         dist.resize(nv);
         bool any_out = false;
@@ -488,6 +491,51 @@ int nt_kdtree_build(int dimension, int n_items, const float *item_lo, const floa
     }
     for (int k = 0; k < n; ++k) { out->aabb[k] = (float)lo[k]; out->aabb[n + k] = (float)hi[k]; }
     return NT_OK;
+}
+
+int nt_polytope_clip_box(int dimension, int n_verts, const float *verts, const uint64_t *tight, int shared_for_edge, int first_free_bit,
+                         const float *lo, const float *hi, float *out_lo, float *out_hi) {
+    if (dimension < 1 || dimension > KD_CLIP_DIM || n_verts < 1 || !verts || !tight || !lo || !hi) return NT_E_INVALID;
+    if (first_free_bit < 0 || first_free_bit + 2 * dimension > 192 || shared_for_edge < 0) return NT_E_INVALID;
+    const int n = dimension;
+    Builder b;
+    b.n = n;
+    double scale = 1.0;
+    for (int i = 0; i < n_verts * n; ++i) scale = std::max(scale, (double)std::fabs(verts[i]));
+    for (int k = 0; k < n; ++k) scale = std::max(scale, (double)std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+    b.scale = scale;
+    try {
+        Refs cur, next;
+        cur.begin(n);
+        for (int i = 0; i < n_verts; ++i) {
+            for (int k = 0; k < n; ++k) cur.vx.push_back(verts[(size_t)i * n + k]);
+            cur.vt.insert(cur.vt.end(), tight + (size_t)i * 3, tight + (size_t)i * 3 + 3);
+        }
+        cur.vert_first.push_back(n_verts);
+        int nv = n_verts;
+        for (int a = 0; a < n && nv > 0; ++a)
+            for (int side = 0; side < 2 && nv > 0; ++side) {
+                next.begin(n);
+                next.vx.clear();
+                next.vt.clear();
+                if (!b.cut_general(cur.vx.data(), cur.vt.data(), nv, a, side == 0 ? 1.0 : -1.0, side == 0 ? lo[a] : hi[a],
+                                   first_free_bit + 2 * a + side, shared_for_edge, next))
+                    return NT_E_NOMEM;                                      // outgrew the vertex budget
+                nv = (int)(next.vx.size() / n);
+                cur.vx.swap(next.vx);
+                cur.vt.swap(next.vt);
+            }
+        if (nv > 0 && out_lo && out_hi)
+            for (int k = 0; k < n; ++k) {
+                double mn = cur.vx[k], mx = cur.vx[k];
+                for (int v = 1; v < nv; ++v) { mn = std::min(mn, cur.vx[(size_t)v * n + k]); mx = std::max(mx, cur.vx[(size_t)v * n + k]); }
+                out_lo[k] = (float)mn;
+                out_hi[k] = (float)mx;
+            }
+        return nv;
+    } catch (const std::bad_alloc &) {
+        return NT_E_NOMEM;
+    }
 }
 
 void nt_kdtree_free(nt_kdtree *t) {

@@ -204,6 +204,16 @@ class Material(object):
         return (tuple(self.color), tuple(self.specular), self.opacity, self.reflectivity, self.specular_intensity,
                 self.specular_exp)
 
+    def __eq__(self, o):
+        return self._key() == o._key() if isinstance(o, Material) else NotImplemented
+
+    def __ne__(self, o):
+        r = self.__eq__(o)
+        return r if r is NotImplemented else not r
+
+    def __hash__(self):
+        return hash(self._key())
+
     def __reduce__(self):
         return _material_unpickle, (_encode_floats(tuple(self.color) + tuple(self.specular) + (
             self.opacity, self.reflectivity, self.specular_intensity, self.specular_exp)),)

@@ -194,8 +194,10 @@ class Matrix(object):
     def __iter__(self):
         return (self[i] for i in range(len(self)))
 
+    @property
     def values(self):
-        return [float(x) for x in self._m.ravel()]
+        """all elements, row-major (an attribute in the reference: ntracer_body.hpp:2330-2345)"""
+        return tuple(float(x) for x in self._m.ravel())
 
     def __mul__(self, o):
         if isinstance(o, Matrix):
@@ -215,7 +217,7 @@ class Matrix(object):
         return isinstance(o, Matrix) and bool(np.array_equal(self._m, o._m))
 
     def __repr__(self):
-        return "Matrix(%d,%r)" % (len(self), self.values())
+        return "Matrix(%d,%r)" % (len(self), list(self.values))
 
 
 def _matmul(a, bt):
@@ -312,6 +314,55 @@ class AABB(object):
     def __reduce__(self):                               # obj_AABB_reduce, render.cpp:1745-1752
         return _render._aabb_unpickle, (self.dimension, _render._encode_floats(np.concatenate([self.start._v, self.end._v])))
 
+    def __eq__(self, o):
+        if not isinstance(o, AABB):
+            return NotImplemented
+        return self.start == o.start and self.end == o.end
+
+    def __ne__(self, o):
+        r = self.__eq__(o)
+        return r if r is NotImplemented else not r
+
+    __hash__ = None
+
+    def _check_axis(self, axis):
+        axis = int(axis)
+        if axis < 0 or axis >= self.dimension:
+            raise IndexError("index out of range")
+        return axis
+
+    def left(self, axis, split):
+        """AABB.left(axis,split): the part below the split (ntracer_body.hpp:2498-2513, tracer.hpp:1337-1343)."""
+        axis = self._check_axis(axis)
+        split = float(split)
+        if not (self.start[axis] < split < self.end[axis]):
+            raise ValueError("\"split\" must be inside the box within the given axis")
+        e = self.end._v.copy()
+        e[axis] = split
+        return AABB(self.dimension, self.start._v, e)
+
+    def right(self, axis, split):
+        """AABB.right(axis,split): the part above the split."""
+        axis = self._check_axis(axis)
+        split = float(split)
+        if not (self.start[axis] < split < self.end[axis]):
+            raise ValueError("\"split\" must be inside the box within the given axis")
+        b = self.start._v.copy()
+        b[axis] = split
+        return AABB(self.dimension, b, self.end._v)
+
+    def intersects(self, primitive):
+        """AABB.intersects(prototype) -> bool: whether the box and the primitive share a region of non-zero extent
+        (two things that merely touch do not intersect; tracer.hpp:1459-1463).  The reference answers with
+        projection tests (:1465-1700); here the primitive is clipped to the box exactly (nt_polytope_clip_box):
+        a simplex as a polytope in its own plane, a cube solid as a parallelotope; a sphere solid by the distance
+        from its centre to the box in the solid's own coordinates."""
+        if not isinstance(primitive, PrimitivePrototype):
+            raise TypeError("object is not an instance of PrimitivePrototype")
+        if primitive.dimension != self.dimension:
+            raise TypeError("cannot perform intersection test on object with different dimension")
+        return primitive._overlaps(self.start._v.astype(np.float64), self.end._v.astype(np.float64))
+
 
 class PointLight(object):
     """tracern.PointLight(position,color) -- tracer.hpp:1678-1689."""
@@ -376,6 +427,17 @@ class Triangle(Primitive):
 
     def _rows(self):
         return np.vstack([self.p1._v, self.face_normal._v] + [e._v for e in self.edge_normals])      # [n+1][n]
+
+    def __eq__(self, o):
+        if not isinstance(o, Triangle):
+            return NotImplemented
+        return self.dimension == o.dimension and np.array_equal(self._rows(), o._rows()) and self.material == o.material
+
+    def __ne__(self, o):
+        r = self.__eq__(o)
+        return r if r is NotImplemented else not r
+
+    __hash__ = object.__hash__
 
     def __reduce__(self):                               # obj_Triangle_reduce, ntracer_body.hpp:1217-1233
         return _render._triangle_unpickle, (self.dimension, _render._encode_floats(self._rows().ravel()), self.material)
@@ -883,6 +945,30 @@ def cross(vectors):
     return Vector._wrap(builder.cross([v._v if isinstance(v, Vector) else list(v) for v in vs]).astype(f32))
 
 
+def _clip_overlaps(n, verts, tight, shared, first_free, lo, hi):
+    """nt_polytope_clip_box against the box shrunk by a hair: what merely touches the box is left with nothing."""
+    v = np.ascontiguousarray(verts, f32)
+    t = np.ascontiguousarray(tight, np.uint64)
+    scale = max(1.0, float(np.abs(v).max()), float(np.abs(lo).max()), float(np.abs(hi).max()))
+    eps = 1e-6 * scale
+    l = np.ascontiguousarray(lo + eps, f32)
+    h = np.ascontiguousarray(hi - eps, f32)
+    if (l >= h).any():
+        return False
+    r = _lib.check(_lib.lib().nt_polytope_clip_box(n, len(v), v.ctypes.data_as(_lib.f32p), t.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   shared, first_free, l.ctypes.data_as(_lib.f32p), h.ctypes.data_as(_lib.f32p), None, None))
+    return r > 0
+
+
+def _simplex_tight(n):
+    t = np.zeros((n, 3), np.uint64)
+    for i in range(n):
+        for j in range(n):
+            if j != i:
+                t[i, j >> 6] |= np.uint64(1) << np.uint64(j & 63)
+    return t
+
+
 class PrimitivePrototype(object):
     """Base of the objects build_kdtree consumes: a primitive plus its bounding box (tracer.hpp:1363-1373)."""
     boundary = None
@@ -896,21 +982,110 @@ class PrimitivePrototype(object):
     def material(self):
         return self.primitive.material
 
+    def _overlaps(self, lo, hi):
+        return bool(((self.boundary.start._v < hi) & (self.boundary.end._v > lo)).all())
+
+
+class TrianglePointData(object):
+    """One vertex of a TrianglePrototype: ``point`` and the edge normal that belongs to it (tracer.hpp:1384-1389)."""
+    __slots__ = ("point", "edge_normal")
+
+    def __init__(self, point, edge_normal):
+        self.point = point
+        self.edge_normal = edge_normal
+
+    def __iter__(self):                    # lets callers that expect plain points unpack the coordinates
+        return iter(self.point)
+
+
+def _point_data(tri, pts):
+    # vertex 0 belongs to the edge normal that is minus the sum of the others (the barycentric gradients add up to 0)
+    first = Vector._wrap(-np.sum([e._v for e in tri.edge_normals], axis=0))
+    return tuple(TrianglePointData(Vector._wrap(pts[k]), first if k == 0 else tri.edge_normals[k - 1]) for k in range(len(pts)))
+
 
 class TrianglePrototype(PrimitivePrototype):
-    """tracern.TrianglePrototype(points[,material]) -- tracer.hpp:1391-1405."""
+    """tracern.TrianglePrototype(points[,material]) or TrianglePrototype(triangle) -- tracer.hpp:1391-1405,
+    ntracer_body.hpp:2680-2760."""
 
     def __init__(self, points, material=None):
-        pts = [list(p) for p in points]
-        if material is None:
-            # the reference also accepts (point, edge_normal) pairs from an existing prototype; not mirrored
-            raise TypeError("material is required")
-        self.primitive = Triangle.from_points(pts, material)
-        a = np.asarray(pts, f32)
+        if isinstance(points, Triangle):
+            if material is not None:
+                raise TypeError("material is taken from the triangle")
+            self.primitive = points
+            a = builder.vertices_of(points.p1._v, points.face_normal._v, [e._v for e in points.edge_normals])
+        else:
+            pts = [list(p) for p in points]
+            if material is None:
+                raise TypeError("material is required")
+            self.primitive = Triangle.from_points(pts, material)
+            a = np.asarray(pts, f32)
         n = a.shape[1]
         self.boundary = AABB(n, a.min(axis=0), a.max(axis=0))
         self.face_normal = self.primitive.face_normal
-        self.point_data = tuple(Vector._wrap(p) for p in a)
+        self.point_data = _point_data(self.primitive, a)
+
+    def _vertices(self):
+        return np.asarray([list(pd.point) for pd in self.point_data], f32)
+
+    def _overlaps(self, lo, hi):
+        n = self.dimension
+        if not PrimitivePrototype._overlaps(self, lo, hi):
+            return False
+        return _clip_overlaps(n, self._vertices(), _simplex_tight(n), n - 2, n, lo, hi)
+
+
+class _LaneView(object):
+    """x[i] of a batch prototype's per-lane attribute"""
+    __slots__ = ("_items",)
+
+    def __init__(self, items):
+        self._items = tuple(items)
+
+    def __getitem__(self, i):
+        return self._items[i]
+
+    def __len__(self):
+        return len(self._items)
+
+
+class TriangleBatchPointData(object):
+    __slots__ = ("point", "edge_normal")
+
+    def __init__(self, point, edge_normal):
+        self.point = point
+        self.edge_normal = edge_normal
+
+
+class TriangleBatchPrototype(PrimitivePrototype):
+    """tracern.TriangleBatchPrototype(triangle_prototypes | TriangleBatch) -- tracer.hpp:1406-1437: BATCH_SIZE
+    triangle prototypes side by side; ``face_normal[i]``, ``point_data[j].point[i]``, ``point_data[j].edge_normal[i]``
+    and ``material[i]`` address lane i."""
+
+    def __init__(self, t_prototypes):
+        if isinstance(t_prototypes, TriangleBatch):
+            protos = [TrianglePrototype(t) for t in t_prototypes]
+            self.primitive = t_prototypes
+        else:
+            protos = list(t_prototypes)
+            if len(protos) != BATCH_SIZE or not all(isinstance(p, TrianglePrototype) for p in protos):
+                raise ValueError("exactly %d TrianglePrototype instances are required" % BATCH_SIZE)
+            self.primitive = TriangleBatch([p.primitive for p in protos])
+        n = protos[0].dimension
+        if any(p.dimension != n for p in protos):
+            raise TypeError("the prototypes must have the same dimension")
+        self._protos = tuple(protos)
+        self.boundary = AABB(n, np.min([p.boundary.start._v for p in protos], axis=0), np.max([p.boundary.end._v for p in protos], axis=0))
+        self.face_normal = _LaneView(p.face_normal for p in protos)
+        self.point_data = tuple(TriangleBatchPointData(_LaneView(p.point_data[j].point for p in protos),
+                                                       _LaneView(p.point_data[j].edge_normal for p in protos)) for j in range(n))
+
+    @property
+    def material(self):
+        return _LaneView(p.material for p in self._protos)
+
+    def _overlaps(self, lo, hi):
+        return PrimitivePrototype._overlaps(self, lo, hi) and any(p._overlaps(lo, hi) for p in self._protos)
 
 
 def triangle_prototypes(simplices, material):
@@ -927,7 +1102,7 @@ def triangle_prototypes(simplices, material):
         tp.primitive = Triangle(p1[k], fn[k], edges[k], material)
         tp.boundary = AABB(n, a[k].min(axis=0), a[k].max(axis=0))
         tp.face_normal = tp.primitive.face_normal
-        tp.point_data = tuple(Vector._wrap(q) for q in a[k])
+        tp.point_data = _point_data(tp.primitive, a[k])
         out.append(tp)
     return out
 
@@ -943,6 +1118,31 @@ class SolidPrototype(PrimitivePrototype):
         self.position = self.primitive.position
         self.orientation = orientation
         self.inv_orientation = self.primitive.inv_orientation
+
+    def _overlaps(self, lo, hi):
+        n = self.dimension
+        if not PrimitivePrototype._overlaps(self, lo, hi):
+            return False
+        o = self.orientation._m.astype(np.float64)
+        pos = self.position._v.astype(np.float64)
+        if self.type == CUBE:
+            # x = O (u + p), u in [-1,1]^n: a parallelotope; vertex facets: bit 2k (+1 for the upper side of axis k)
+            signs = np.array([[1.0 if (m >> k) & 1 else -1.0 for k in range(n)] for m in range(1 << n)])
+            verts = (signs + pos) @ o.T
+            tight = np.zeros((1 << n, 3), np.uint64)
+            for m in range(1 << n):
+                for k in range(n):
+                    bit = 2 * k + ((m >> k) & 1)
+                    tight[m, bit >> 6] |= np.uint64(1) << np.uint64(bit & 63)
+            return _clip_overlaps(n, verts, tight, n - 1, 2 * n, lo, hi)
+        # sphere: minimise |O^-1 x - p|^2 over the box (convex) by projected gradient from the clamped centre
+        inv = self.inv_orientation._m.astype(np.float64)
+        x = np.clip(o @ pos, lo, hi)
+        step = 1.0 / max(1e-12, 2.0 * np.linalg.norm(inv, 2) ** 2)
+        for _ in range(200):
+            g = 2.0 * inv.T @ (inv @ x - pos)
+            x = np.clip(x - step * g, lo, hi)
+        return bool(np.linalg.norm(inv @ x - pos) < 1.0 - 1e-9)
 
 
 def build_kdtree(primitives, extra_threads=-1, **kwds):
@@ -964,7 +1164,7 @@ def build_kdtree(primitives, extra_threads=-1, **kwds):
     n = protos[0].dimension
     if any(p.dimension != n for p in protos):
         raise TypeError("the primitive prototypes must all have the same dimension")
-    tri = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v, [[list(q) for q in p.point_data]]) for p in protos
+    tri = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v, [p._vertices()]) for p in protos
            if isinstance(p, TrianglePrototype)]
     other = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v) for p in protos if not isinstance(p, TrianglePrototype)]
     batches, loose = builder.group_batches(tri, BATCH_SIZE, TriangleBatch)

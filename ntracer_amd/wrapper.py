@@ -27,7 +27,7 @@ class _VectorFactory(object):
 
     def __call__(self, *values):
         if len(values) == 1 and not isinstance(values[0], (int, float)):
-            values = values[0]
+            values = list(values[0])           # any iterable, generators included
         if len(values) == 0:
             return tracern.Vector(self._dim)
         return tracern.Vector(self._dim, values)
@@ -42,7 +42,7 @@ class _MatrixFactory(object):
 
     def __call__(self, *values):
         if len(values) == 1:
-            values = values[0]
+            values = list(values[0])
         return tracern.Matrix(self._dim, values)
 
     def identity(self):
@@ -77,7 +77,8 @@ class NTracer(object):
         obj.BoxScene = _bind_dimension(tracern.BoxScene, dimension)
         obj.AABB = _bind_dimension(tracern.AABB, dimension)
         for n in ("CompositeScene", "KDNode", "KDLeaf", "KDBranch", "Primitive", "PrimitiveBatch", "Solid", "Triangle",
-                  "TriangleBatch", "TrianglePrototype", "SolidPrototype", "PrimitivePrototype", "PointLight", "GlobalLight",
+                  "TriangleBatch", "TrianglePrototype", "TriangleBatchPrototype", "SolidPrototype", "PrimitivePrototype", "PointLight",
+                  "GlobalLight",
                   "dot", "cross", "build_kdtree", "build_composite_scene",
                   "screen_coord_to_ray", "BATCH_SIZE"):
             setattr(obj, n, getattr(tracern, n))

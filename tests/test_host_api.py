@@ -46,7 +46,7 @@ def test_vector_matrix_basics():
     assert abs(v.unit().absolute() - 1) < 1e-6
     m = nt.Matrix.rotation(nt.Vector.axis(0), nt.Vector.axis(1), 0.3)
     i = m * m.inverse()
-    assert np.abs(np.array(i.values()).reshape(4, 4) - np.eye(4)).max() < 1e-6
+    assert np.abs(np.array(i.values).reshape(4, 4) - np.eye(4)).max() < 1e-6
     assert list(nt.Matrix.identity() * v) == list(v)
     with pytest.raises(TypeError):
         tracern.dot(v, nt.Vector.axis(0) if False else tracern.Vector(3))
