@@ -503,7 +503,7 @@ class CallbackRenderer(object):
 
 def get_optimized_tracern(dimension):
     """render.get_optimized_tracern(dimension) -- render.cpp:1659-1674.  The specialisation for
-    3..8 dimensions happens inside the HIP library (template<int N> kernels); the Python surface is
+    3..10 dimensions happens inside the HIP library (template<int N> kernels); the Python surface is
     one module."""
     from . import tracern
     return tracern

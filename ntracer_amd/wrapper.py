@@ -61,7 +61,7 @@ class _MatrixFactory(object):
 class NTracer(object):
     """NTracer(dimension[,force_generic=False]): helper that creates objects of one dimension.
     ``force_generic`` is accepted for compatibility: the fixed-N vs run-time-n choice is made inside
-    the HIP library (template<int N> kernels for 3..8, LDS-staged run-time-n kernel otherwise)."""
+    the HIP library (template<int N> kernels for 3..10, LDS-staged run-time-n kernel otherwise)."""
     _cache = weakref.WeakValueDictionary()
 
     def __new__(cls, dimension, force_generic=False):

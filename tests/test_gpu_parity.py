@@ -532,7 +532,7 @@ def test_reference_known_answer_scene_on_gpu():
 
 
 def test_lights_shadows_reflection_solids_vs_oracle():
-    """feature scene with every material made opaque (transparency is not on the GPU path yet): lights,
+    """feature scene with every material made opaque (transparency: see test_transparency_vs_oracle): lights,
     shadows incl. the far-child quirk, reflection to depth 4/1/0, Solid cube + spheres, unbatched
     triangles.  Oracle in clean-normal mode (see oracle header for the aliasing it otherwise mimics)."""
     g = fx.load("feature3d")
