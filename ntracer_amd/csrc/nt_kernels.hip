@@ -366,29 +366,11 @@ __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir
     }
 }
 
+// One pixel of BoxScene from the unnormalised direction `dir` (|dir|^2 = sq), sx / sy as in the ray source.
 template <int N>
-__global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg) {
-    const int tid = (int)threadIdx.x;
-    const PixelRef pr = locate_pixel<64, 4>(tg, tid & 63, tid >> 6, tid);
-    if (!pr.valid) return;
-    float org[N], right[N], up[N], fwd[N], dir[N];
-    load_camera<N>(cam, org, right, up, fwd);
-    // flat_origin_ray_source::operator() (tracer.hpp:71-75), as primary_dir, with the normalisation split off
-    const float sx = tg.fovI * ((float)pr.x - tg.half_w);
-    const float sy = tg.fovI * ((float)pr.y - tg.half_h);
-#pragma unroll
-    for (int j = 0; j < N; ++j) dir[j] = (fwd[j] + right[j] * sx) - up[j] * sy;
-    float sq = dir[0] * dir[0];
-#pragma unroll
-    for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+__device__ __forceinline__ void box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
+                                          const float (&dots)[4], float sx, float sy) {
     const float len = sqrtf(sq);
-    float dots[4];
-    if (cam.buf) {
-        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
-        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
-    } else {
-        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
-    }
     const bool maybe = box_may_hit(N, dots, sx, sy, sq);
     float r, g, b;
     if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) {
@@ -410,6 +392,71 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         }
     }
     emit_pixel(tg, pr, r, g, b);
+}
+
+// A lane renders BoxRows<N> = 4 pixels of one image column (a block: 64 columns x 16 rows; a wave still writes 64
+// consecutive pixels of a row at a time): forward + right*sx is the same for all of them, which takes a tenth of
+// the instructions off the path most rays take.
+// (n <= 8; beyond that the extra registers cost more than the shared work saves: measured on n = 10)
+template <int N> struct BoxRows { static constexpr int value = N <= 8 ? 4 : 1; };
+template <int N>
+__global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg) {
+    const int tid = (int)threadIdx.x;
+    float org[N], right[N], up[N], fwd[N], dir[N];
+    load_camera<N>(cam, org, right, up, fwd);
+    float dots[4];
+    if (cam.buf) {
+        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
+    } else {
+        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
+    }
+    if (tg.colors_out || BoxRows<N>::value == 1) {
+        // one pixel per lane: probe mode (listed pixels), and n > 8
+        const PixelRef pr = locate_pixel<64, 4>(tg, tid & 63, tid >> 6, tid);
+        if (!pr.valid) return;
+        // flat_origin_ray_source::operator() (tracer.hpp:71-75), as primary_dir, with the normalisation split off
+        const float sx = tg.fovI * ((float)pr.x - tg.half_w);
+        const float sy = tg.fovI * ((float)pr.y - tg.half_h);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dir[j] = (fwd[j] + right[j] * sx) - up[j] * sy;
+        float sq = dir[0] * dir[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+        box_pixel<N>(tg, pr, org, dir, sq, dots, sx, sy);
+        return;
+    }
+    const int x = (int)blockIdx.x * 64 + (tid & 63);
+    if (x >= tg.width) return;
+    const float sx = tg.fovI * ((float)x - tg.half_w);
+    float base[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
+    const int row0 = ((int)blockIdx.y * 4 + (tid >> 6)) * BoxRows<N>::value;
+    for (int rr = 0; rr < BoxRows<N>::value; ++rr) {
+        const int row = row0 + rr;                      // relative to row_begin; the same for the whole wave
+        if (row >= tg.row_count) return;
+        const int orow = tg.row_begin + row;
+        int y = orow;
+        if (tg.band_world > 1) {
+            const int band = orow / tg.band_rows;
+            y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+        }
+        if (y >= tg.height) continue;
+        PixelRef pr;
+        pr.x = x;
+        pr.y = y;
+        pr.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+        pr.hit_index = 0;
+        pr.valid = true;
+        const float sy = tg.fovI * ((float)y - tg.half_h);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+        float sq = dir[0] * dir[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+        box_pixel<N>(tg, pr, org, dir, sq, dots, sx, sy);
+    }
 }
 
 // --------------------------------------------------------------------------------------
@@ -2714,7 +2761,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     cf.n = N;
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];
     dim3 grid;
-    grid_for(tg, 64, 4, li.nframes, grid);
+    grid_for(tg, 64, tg.colors_out ? 4 : 4 * BoxRows<N>::value, li.nframes, grid);
     hipLaunchKernelGGL(box_kernel<N>, grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
     return 0;
 }
