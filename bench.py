@@ -287,10 +287,10 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
 
     chan = [ntracer_amd.Channel(*c) for c in RGBX8]
     g = np.load(os.path.join(G, "box_n3_1920x1080.npz"))
-    ms = time_scene(tracern.BoxScene(3), ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"], g["axes"], 32, 5)
+    ms = time_scene(tracern.BoxScene(3), ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"], g["axes"], 32, 25)
     res["config1_box3_1080p_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
     g = np.load(os.path.join(G, "box_n10_4096x4096.npz"))
-    ms = time_scene(tracern.BoxScene(10), ntracer_amd.ImageFormat(4096, 4096, chan), g["origins"], g["axes"], 4, 5)
+    ms = time_scene(tracern.BoxScene(10), ntracer_amd.ImageFormat(4096, 4096, chan), g["origins"], g["axes"], 4, 10)
     res["config5_box10_4096_Mrays_s"] = round(4096 * 4096 / ms / 1e3, 1)
     g = np.load(os.path.join(G, "cell120_n4.npz"))
     sc = tracern.CompositeScene.from_flat(4, g)
