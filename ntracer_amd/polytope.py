@@ -320,7 +320,8 @@ def main(argv=None):
             ap.error("fov must be between 0 and 180 degrees")
         scene.set_fov(a.fov / 180 * math.pi)
     print("scene built in %.2f s" % (time.perf_counter() - t0))
-    fmt = ImageFormat(w, h, [Channel(8, 1, 0, 0), Channel(8, 0, 1, 0), Channel(8, 0, 0, 1)])
+    # RGBX8: 4-byte pixels are written with one coalesced dword per lane (3-byte pixels fall back to byte stores)
+    fmt = ImageFormat(w, h, [Channel(8, 1, 0, 0), Channel(8, 0, 1, 0), Channel(8, 0, 0, 1), Channel(8, 0, 0, 0)])
     buf = bytearray(fmt.pitch * h)
     r = BlockingRenderer()
     if a.output:
@@ -332,7 +333,7 @@ def main(argv=None):
         r.render(buf, fmt, scene)
         total += time.perf_counter() - t
         if a.output:
-            _write_png(os.path.join(a.output, "frame%05d.png" % f), np.frombuffer(bytes(buf), np.uint8).reshape(h, fmt.pitch)[:, :w * 3].reshape(h, w, 3))
+            _write_png(os.path.join(a.output, "frame%05d.png" % f), np.ascontiguousarray(np.frombuffer(bytes(buf), np.uint8).reshape(h, fmt.pitch)[:, :w * 4].reshape(h, w, 4)[:, :, :3]))
     if a.benchmark:
         print("rendered %d frame(s) in %g seconds\ntime per frame: %g seconds\nframes per second: %g"
               % (a.frames, total, total / a.frames, a.frames / total))
