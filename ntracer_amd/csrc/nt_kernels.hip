@@ -135,6 +135,30 @@ __device__ __forceinline__ void store_pixel(uint8_t *p, const NtTarget &tg, uint
     }
 }
 
+// A pixel that fits one 32-bit word but is not 4 bytes wide.  3-byte pixels (RGB24) of four neighbouring lanes --
+// every image kernel puts x = ...+lane within aligned groups of 8 or 64 -- are 12 contiguous bytes: three of the
+// four lanes assemble one dword each from their own and their right neighbour's pixel and store it; anything else
+// (other widths, unaligned rows, a group cut by the image edge) goes out byte by byte.
+__device__ __forceinline__ void store_word32_narrow(uint8_t *p, const NtTarget &tg, uint32_t w, int x) {
+    if (tg.bpp == 3 && tg.aligned4 && !tg.colors_out) {
+        const int lane = (int)(threadIdx.x & 63);
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);          // lanes executing this store
+        const bool whole = ((act >> (lane & ~3)) & 0xfull) == 0xfull && (x & 3) == (lane & 3);
+        // the pixel's three bytes in memory order, lowest first
+        const uint32_t m = tg.reversed ? (w >> 8) : (bswap32(w) & 0xffffffu);
+        const uint32_t right = (uint32_t)__shfl_down((int)m, 1, 64);
+        if (whole) {
+            const int j = lane & 3;
+            if (j < 3) {
+                const uint32_t dw = (m >> (8 * j)) | (right << (24 - 8 * j));
+                *reinterpret_cast<uint32_t *>(p + j) = dw;          // p = row + 3x; the group's dword j sits at row + 3*(x-j) + 4j = p + j
+            }
+            return;
+        }
+    }
+    store_pixel(p, tg, (uint64_t)w << 32, 0);
+}
+
 // --------------------------------------------------------------------------------------
 // pixel <-> thread mapping (worker_draw's chunking, render.cpp:468-493, becomes the grid)
 // --------------------------------------------------------------------------------------
@@ -201,7 +225,7 @@ __device__ __forceinline__ void emit_pixel(const NtTarget &tg, const PixelRef &p
             *reinterpret_cast<uint32_t *>(p) = tg.reversed ? w : bswap32(w);     // one coalesced dword per lane
             return;
         }
-        store_pixel(p, tg, (uint64_t)w << 32, 0);
+        store_word32_narrow(p, tg, w, pr.x);
         return;
     }
     if (tg.pack_mode == NT_PACK_WORD64) {
@@ -2729,7 +2753,7 @@ __global__ __launch_bounds__(256, FEAT ? 1 : ((N <= 4 && !SCAL) ? 6 : (N <= 7 ? 
         if (tg.pack_mode == NT_PACK_WORD32) {
             const uint32_t wd = pack_word32(c.r, c.g, c.b, tg);
             if (tg.bpp == 4 && tg.aligned4) *reinterpret_cast<uint32_t *>(p) = tg.reversed ? wd : bswap32(wd);
-            else store_pixel(p, tg, (uint64_t)wd << 32, 0);
+            else store_word32_narrow(p, tg, wd, x);
         } else if (tg.pack_mode == NT_PACK_WORD64) {
             store_pixel(p, tg, pack_word64(c.r, c.g, c.b, tg), 0);
         } else {

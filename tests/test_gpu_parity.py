@@ -508,6 +508,34 @@ def test_band_heights_other_than_32(band_rows, world):
         assert np.array_equal(re, whole)
 
 
+@pytest.mark.parametrize("w,h,pitch", [(64, 8, 0), (333, 9, 1000), (333, 9, 0), (1920, 16, 0), (5, 3, 16)])
+@pytest.mark.parametrize("rev", [False, True])
+def test_three_byte_pixels_are_packed_across_lanes(w, h, pitch, rev):
+    """RGB24: four neighbouring lanes turn their 3-byte pixels into three dword stores when the rows are 4-byte
+    aligned (store_word32_narrow), byte stores otherwise (odd pitches, groups cut by the image edge).  Same bytes as
+    the oracle either way: BoxScene (exact) and a composite scene through the packet and tile kernels (+-1)."""
+    rgb24 = [(8, 1, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1)]
+    gb = fx.load("box_n6_1920x1080")
+    fmt = fmt_of(w, h, rgb24, pitch, rev)
+    sc = tracern.BoxScene(6)
+    sc._set_camera_arrays(gb["origins"][17], gb["axes"][17])
+    buf = bytearray(b"\xa5" * (fmt.pitch * h))
+    assert ntracer_amd.BlockingRenderer().render(buf, fmt, sc)
+    got = np.frombuffer(bytes(buf), np.uint8).reshape(h, fmt.pitch)
+    ref = ob.OracleScene(6, gb["origins"][17], gb["axes"][17]).render(w, h, rgb24, pitch=fmt.pitch, reversed_=rev)
+    assert np.array_equal(got[:, :w * 3], ref[:, :w * 3])
+    assert (got[:, w * 3:] == 0xa5).all()                  # padding bytes of the rows are left alone
+    g = fx.load("cell600_n4")
+    flat = fx.flat_of(g)
+    cs = tracern.CompositeScene.from_flat(4, flat)
+    cs._set_camera_arrays(g["origins"][33], g["axes"][33])
+    buf = bytearray(fmt.pitch * h)
+    assert ntracer_amd.BlockingRenderer().render(buf, fmt, cs)
+    got = np.frombuffer(bytes(buf), np.uint8).reshape(h, fmt.pitch)[:, :w * 3]
+    ref = ob.OracleScene(4, g["origins"][33], g["axes"][33], flat=flat).render(w, h, rgb24, pitch=fmt.pitch, reversed_=rev)[:, :w * 3]
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
