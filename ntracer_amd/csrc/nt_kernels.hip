@@ -159,6 +159,30 @@ __device__ __forceinline__ void store_word32_narrow(uint8_t *p, const NtTarget &
     store_pixel(p, tg, (uint64_t)w << 32, 0);
 }
 
+// The same for 6-byte pixels (three 16-bit channels, the format of the reference's video export,
+// scripts/polytope.py:594-599): two neighbouring lanes own 12 contiguous bytes = three dwords.
+__device__ __forceinline__ void store_word64_narrow(uint8_t *p, const NtTarget &tg, uint64_t w, int x) {
+    if (tg.bpp == 6 && tg.aligned4 && !tg.colors_out) {
+        const int lane = (int)(threadIdx.x & 63);
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+        const bool whole = ((act >> (lane & ~1)) & 0x3ull) == 0x3ull && (x & 1) == (lane & 1);
+        // the pixel's six bytes in memory order, lowest first (w holds them MSB-first in its top 48 bits)
+        const uint64_t m = tg.reversed ? (w >> 16) : (__builtin_bswap64(w) & 0xffffffffffffull);
+        const uint32_t right_lo = (uint32_t)__shfl_down((int)(uint32_t)m, 1, 64);
+        if (whole) {
+            if ((lane & 1) == 0) {                          // p = pair base: bytes 0..7
+                uint32_t *q = reinterpret_cast<uint32_t *>(p);
+                q[0] = (uint32_t)m;
+                q[1] = (uint32_t)(m >> 32) | (right_lo << 16);
+            } else {                                        // p = pair base + 6: its bytes 2..5 are the pair's last dword
+                *reinterpret_cast<uint32_t *>(p + 2) = (uint32_t)(m >> 16);
+            }
+            return;
+        }
+    }
+    store_pixel(p, tg, w, 0);
+}
+
 // --------------------------------------------------------------------------------------
 // pixel <-> thread mapping (worker_draw's chunking, render.cpp:468-493, becomes the grid)
 // --------------------------------------------------------------------------------------
@@ -229,7 +253,7 @@ __device__ __forceinline__ void emit_pixel(const NtTarget &tg, const PixelRef &p
         return;
     }
     if (tg.pack_mode == NT_PACK_WORD64) {
-        store_pixel(p, tg, pack_word64(r, g, b, tg), 0);
+        store_word64_narrow(p, tg, pack_word64(r, g, b, tg), pr.x);
         return;
     }
     uint64_t hi, lo;
@@ -2755,7 +2779,7 @@ __global__ __launch_bounds__(256, FEAT ? 1 : ((N <= 4 && !SCAL) ? 6 : (N <= 7 ? 
             if (tg.bpp == 4 && tg.aligned4) *reinterpret_cast<uint32_t *>(p) = tg.reversed ? wd : bswap32(wd);
             else store_word32_narrow(p, tg, wd, x);
         } else if (tg.pack_mode == NT_PACK_WORD64) {
-            store_pixel(p, tg, pack_word64(c.r, c.g, c.b, tg), 0);
+            store_word64_narrow(p, tg, pack_word64(c.r, c.g, c.b, tg), x);
         } else {
             uint64_t hi, lo;
             pack_pixel(c.r, c.g, c.b, tg, hi, lo);

@@ -536,6 +536,36 @@ def test_three_byte_pixels_are_packed_across_lanes(w, h, pitch, rev):
     assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("w,h,pitch,rev", [(64, 8, 0, False), (333, 5, 0, True), (333, 5, 2002, False), (7, 3, 48, True)])
+def test_six_byte_pixels_are_packed_across_lane_pairs(w, h, pitch, rev):
+    """RGB48 (three 16-bit channels, the reference's video-export format): lane pairs write three dwords per two
+    pixels on aligned rows (store_word64_narrow); the bytes are the oracle's."""
+    rgb48 = [(16, 1, 0, 0), (16, 0, 1, 0), (16, 0, 0, 1)]
+    gb = fx.load("box_n6_1920x1080")
+    fmt = fmt_of(w, h, rgb48, pitch, rev)
+    sc = tracern.BoxScene(6)
+    sc._set_camera_arrays(gb["origins"][17], gb["axes"][17])
+    buf = bytearray(b"\x5a" * (fmt.pitch * h))
+    assert ntracer_amd.BlockingRenderer().render(buf, fmt, sc)
+    got = np.frombuffer(bytes(buf), np.uint8).reshape(h, fmt.pitch)
+    ref = ob.OracleScene(6, gb["origins"][17], gb["axes"][17]).render(w, h, rgb48, pitch=fmt.pitch, reversed_=rev)
+    assert np.array_equal(got[:, :w * 6], ref[:, :w * 6])
+    assert (got[:, w * 6:] == 0x5a).all()
+    g = fx.load("cell600_n4")
+    flat = fx.flat_of(g)
+    cs = tracern.CompositeScene.from_flat(4, flat)
+    cs._set_camera_arrays(g["origins"][33], g["axes"][33])
+    buf = bytearray(fmt.pitch * h)
+    assert ntracer_amd.BlockingRenderer().render(buf, fmt, cs)
+    got = np.frombuffer(bytes(buf), np.uint8).reshape(h, fmt.pitch)[:, :w * 6].reshape(h, w, 3, 2)
+    ref = ob.OracleScene(4, g["origins"][33], g["axes"][33], flat=flat).render(w, h, rgb48, pitch=fmt.pitch, reversed_=rev)[:, :w * 6].reshape(h, w, 3, 2)
+    to16 = (lambda a: a[..., 1].astype(int) * 256 + a[..., 0]) if rev else (lambda a: a[..., 0].astype(int) * 256 + a[..., 1])
+    gv, rv = to16(got), to16(ref)
+    if rev:                                              # reversed pixels: channel order flips too
+        gv, rv = gv[..., ::-1], rv[..., ::-1]
+    assert np.abs(gv - rv).max() <= 2                    # powf rounding, in 16-bit units
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
