@@ -566,6 +566,50 @@ def test_six_byte_pixels_are_packed_across_lane_pairs(w, h, pitch, rev):
     assert np.abs(gv - rv).max() <= 2                    # powf rounding, in 16-bit units
 
 
+def test_bench_workload_every_frame_equals_the_oracle():
+    """The bench's step itself -- BoxScene(6), 1920x1080 RGBX8, the 160 cameras of the rotation in ONE launch -- against
+    the oracle, frame by frame, byte for byte (the oracle uses the host's cores: a few seconds on the GPU box)."""
+    import os
+    import torch
+    g = fx.load("box_n6_1920x1080")
+    w, h = 1920, 1080
+    fmt = fmt_of(w, h, fx.RGBX8)
+    sc = tracern.BoxScene(6)
+    o = np.ascontiguousarray(g["origins"], np.float32)
+    a = np.ascontiguousarray(g["axes"], np.float32)
+    nf = len(o)
+    fb = torch.zeros((nf, h * fmt.pitch), dtype=torch.uint8, device="cuda")
+    st_ = fmt._as_struct()
+    _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), h * fmt.pitch, nf,
+                                                  o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(st_),
+                                                  None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = fb.cpu().numpy().reshape(nf, h, fmt.pitch)
+    osc = ob.OracleScene(6, o[0], a[0])
+    threads = max(1, min(63, (os.cpu_count() or 2) - 1))
+    step = 1 if threads >= 16 else 8                     # a small host checks every 8th frame
+    for f in range(0, nf, step):
+        osc.set_camera(o[f], a[f])
+        ref = osc.render(w, h, fx.RGBX8, threads=threads)
+        assert np.array_equal(got[f], ref), f
+
+
+@pytest.mark.parametrize("frame", [0, 40, 93])
+def test_cell120_full_1080p_frames_vs_oracle(frame):
+    """config 4 at full size against the oracle on whole frames (the oracle walks with prune_beyond_hit, which its own
+    test shows to be pixel-identical to the reference's walk and is an order of magnitude faster)."""
+    import os
+    g = fx.load("cell120_n4")
+    flat = fx.flat_of(g)
+    sc = tracern.CompositeScene.from_flat(4, flat)
+    sc._set_camera_arrays(g["origins"][frame], g["axes"][frame])
+    img = render_host(sc, fmt_of(1920, 1080, fx.RGBX8))
+    threads = max(1, min(63, (os.cpu_count() or 2) - 1))
+    ref = ob.OracleScene(4, g["origins"][frame], g["axes"][frame], flat=flat, prune=True).render(1920, 1080, fx.RGBX8, threads=threads)
+    d = np.abs(img.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d > 0).sum() < 1e-4 * d.size
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
