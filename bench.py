@@ -289,6 +289,11 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
     g = np.load(os.path.join(G, "box_n3_1920x1080.npz"))
     ms = time_scene(tracern.BoxScene(3), ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"], g["axes"], 32, 25)
     res["config1_box3_1080p_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
+    # config 3 in the other format SURVEY 8d lists: three fp32 channels (12 B/pixel, big-endian floats)
+    g6 = np.load(os.path.join(G, "box_n6_1920x1080.npz"))
+    f32chan = [ntracer_amd.Channel(32, 1, 0, 0, 0, True), ntracer_amd.Channel(32, 0, 1, 0, 0, True), ntracer_amd.Channel(32, 0, 0, 1, 0, True)]
+    ms = time_scene(tracern.BoxScene(6), ntracer_amd.ImageFormat(1920, 1080, f32chan), g6["origins"], g6["axes"], 32, 10)
+    res["config3_box6_1080p_rgbf32_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
     g = np.load(os.path.join(G, "box_n10_4096x4096.npz"))
     ms = time_scene(tracern.BoxScene(10), ntracer_amd.ImageFormat(4096, 4096, chan), g["origins"], g["axes"], 4, 10)
     res["config5_box10_4096_Mrays_s"] = round(4096 * 4096 / ms / 1e3, 1)

@@ -92,6 +92,8 @@ struct Format {                          // validated image_format (render.cpp:1
     // "plain RGB" layouts (every live channel is exactly one of r, g, b, same bit size, one 32-bit word): the three
     // multipliers place a quantised component into all the fields that carry it; 0 bits = not such a layout
     uint32_t plain_bits = 0, plain_maxval = 0, plain_mul[3] = {0, 0, 0};
+    // three fp32 channels, each exactly one of r, g, b (12-byte pixels): component of float k, or -1 if not this layout
+    int plain_f32[3] = {-1, -1, -1};
     std::vector<NtChanDev> chans;        // live channels only (all-zero channels contribute no bits)
 };
 
@@ -163,6 +165,21 @@ int parse_format(const nt_image_format *f, Format &out) {
     out.pack_mode = NT_PACK_GENERIC;
     if (out.chans.size() <= 4 && bits <= 32) out.pack_mode = NT_PACK_WORD32;
     else if (out.chans.size() <= 4 && bits <= 64) out.pack_mode = NT_PACK_WORD64;
+    if (out.chans.size() == 3 && bits == 96) {
+        int comp[3] = {-1, -1, -1};
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; ++k) {
+            const NtChanDev &d = out.chans[k];
+            const float f[3] = {d.f_r, d.f_g, d.f_b};
+            int ones = 0, zeros = 0;
+            for (int c = 0; c < 3; ++c) {
+                if (f[c] == 1.0f) { comp[k] = c; ++ones; }
+                else if (f[c] == 0.0f && !std::signbit(f[c])) ++zeros;
+            }
+            ok = ones == 1 && zeros == 2 && d.f_c == 0.0f && !std::signbit(d.f_c) && d.tfloat && d.offset == (uint32_t)(32 * k);
+        }
+        if (ok) for (int k = 0; k < 3; ++k) out.plain_f32[k] = comp[k];
+    }
     if (out.pack_mode == NT_PACK_WORD32 && !out.chans.empty()) {
         bool plain = true;
         uint32_t mul[3] = {0, 0, 0};
@@ -459,6 +476,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         tg.plain_bits = f.plain_bits;
         tg.plain_maxval = f.plain_maxval;
         for (int k = 0; k < 3; ++k) tg.plain_mul[k] = f.plain_mul[k];
+        for (int k = 0; k < 3; ++k) tg.plain_f32[k] = f.plain_f32[k];
         tg.bpp = f.bpp;
         tg.reversed = f.reversed;
         tg.pitch = f.pitch;

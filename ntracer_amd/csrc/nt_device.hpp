@@ -38,6 +38,7 @@ struct NtTarget {
     // plain RGB layouts in one dword (RGBX8, BGRA8, ...): plain_bits != 0, and component k goes to the fields
     // plain_mul[k] marks (a quantised component times plain_mul[k] is that component shifted into all of them)
     uint32_t plain_bits, plain_maxval, plain_mul[3];
+    int plain_f32[3];         // 12-byte pixels of three fp32 channels that are plain components: component of float k; else -1
     int width, height;        // view size: set_view_size(w,h) (tracer.hpp:65-69)
     float half_w, half_h, fovI;
     int band_rank, band_world, band_rows, compact;

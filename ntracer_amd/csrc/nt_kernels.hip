@@ -256,6 +256,22 @@ __device__ __forceinline__ void emit_pixel(const NtTarget &tg, const PixelRef &p
         store_word64_narrow(p, tg, pack_word64(r, g, b, tg), pr.x);
         return;
     }
+    if (tg.plain_f32[0] >= 0 && tg.aligned4) {
+        // three fp32 channels that are plain components: clamp, big-endian floats (or the reversed pixel)
+        const float c[3] = {r, g, b};
+        uint32_t v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float x = tg.plain_f32[k] == 0 ? c[0] : (tg.plain_f32[k] == 1 ? c[1] : c[2]);
+            x = x > 0.0f ? x : 0.0f;     // simd::clamp, as in channel_value
+            x = x < 1.0f ? x : 1.0f;
+            v[k] = __float_as_uint(x);
+        }
+        uint32_t *q = reinterpret_cast<uint32_t *>(p);
+        if (!tg.reversed) { q[0] = bswap32(v[0]); q[1] = bswap32(v[1]); q[2] = bswap32(v[2]); }
+        else { q[0] = v[2]; q[1] = v[1]; q[2] = v[0]; }
+        return;
+    }
     uint64_t hi, lo;
     pack_pixel(r, g, b, tg, hi, lo);
     store_pixel(p, tg, hi, lo);

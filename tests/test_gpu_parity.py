@@ -610,6 +610,22 @@ def test_cell120_full_1080p_frames_vs_oracle(frame):
     assert d.max() <= 1 and (d > 0).sum() < 1e-4 * d.size
 
 
+@pytest.mark.parametrize("order", [(0, 1, 2), (2, 0, 1)])
+@pytest.mark.parametrize("rev", [False, True])
+def test_three_float_channels_fast_path(order, rev):
+    """fp32 x 3 pixels whose channels are plain components (any order) take a short epilogue: clamp, big-endian
+    float bits, three dword stores.  Bytes equal the oracle's generic packing."""
+    chans = [(32,) + tuple(1.0 if c == k else 0.0 for c in range(3)) + (0.0, True) for k in order]
+    gb = fx.load("box_n6_1920x1080")
+    sc = tracern.BoxScene(6)
+    sc._set_camera_arrays(gb["origins"][29], gb["axes"][29])
+    fmt = fmt_of(401, 33, chans, 0, rev)
+    got = render_host(sc, fmt)
+    ref = ob.OracleScene(6, gb["origins"][29], gb["axes"][29]).render(401, 33, chans, reversed_=rev)
+    assert np.array_equal(got, ref)
+    assert got.max() > 0
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
