@@ -626,6 +626,35 @@ def test_three_float_channels_fast_path(order, rev):
     assert got.max() > 0
 
 
+def test_config4_whole_rotation_default_walk_equals_reference_walk():
+    """All 160 cameras of the 120-cell rotation at 1920x1080: the default walk (cells beyond the hit dropped) and the
+    reference's exact walk (strict_reference) must produce the same bytes, frame for frame; and so must the 600-cell."""
+    import torch
+    for name in ("cell120_n4", "cell600_n4"):
+        g = fx.load(name)
+        sc = tracern.CompositeScene.from_flat(4, fx.flat_of(g))
+        fmt = fmt_of(1920, 1080, fx.RGBX8)
+        st_ = fmt._as_struct()
+        o = np.ascontiguousarray(g["origins"], np.float32)
+        a = np.ascontiguousarray(g["axes"], np.float32)
+        chunk = 40
+        for f0 in range(0, len(o), chunk):
+            out = []
+            for strict in (0, 1):
+                opts = _lib.NtRenderOpts()
+                opts.device = -1
+                opts.band_world = 1
+                opts.strict_reference = strict
+                fb = torch.zeros((chunk, 1080 * fmt.pitch), dtype=torch.uint8, device="cuda")
+                _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), 1080 * fmt.pitch, chunk,
+                                                              o[f0:f0 + chunk].ctypes.data_as(_lib.f32p), a[f0:f0 + chunk].ctypes.data_as(_lib.f32p),
+                                                              C.byref(st_), C.byref(opts), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                torch.cuda.synchronize()
+                out.append(fb)
+            assert torch.equal(out[0], out[1]), (name, f0)
+            assert int(out[0].max()) > 0
+
+
 def test_reference_known_answer_scene_on_gpu():
     """lib/ntracer/tests/test.py:303-363 through the GPU: a camera at the test ray's origin looking along
     its direction; the centre pixel must be shaded exactly as the oracle shades the hit on primitives[4]."""
