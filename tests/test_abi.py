@@ -139,3 +139,19 @@ def test_unsupported_features_are_refused_not_approximated():
     flat = fx.flat_of(fx.load("cell600_n4"))
     with pytest.raises(ValueError):
         tracern.CompositeScene.from_flat(9, flat)                 # record sizes do not match dimension 9
+
+
+def test_header_is_c99_and_links_from_plain_c(tmp_path):
+    """include/ntracer_hip.h must be usable from C (the boundary is a C ABI): gcc -std=c99 compiles tests/c_client.c
+    against it, links libntracer_hip.so, and the program talks to the library."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "c_client")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_client.c"), "-o", exe, "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH),
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([exe]).decode()
+    assert "dimension 6 composite 0" in out and "kdtree: status 0 nodes 1 items 2" in out
