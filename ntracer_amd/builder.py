@@ -222,6 +222,31 @@ def build_tree(items, make_leaf, make_branch, max_depth=KD_DEFAULT_MAX_DEPTH, sp
     """SAH k-d tree over the items, built by the native builder (csrc/nt_builder.cpp, nt_kdtree_build): exact
     clipping of every simplex to every cell it is tested against.  Returns (lo, hi, root) with the nodes made
     through make_leaf(list of prims) / make_branch(axis, split, left, right)."""
+    lo, hi, axis, split, left, right, leaf_items, root = build_tree_arrays(items, max_depth, split_threshold, traversal_cost,
+                                                                           intersection_cost)
+    made = {}
+    # children before parents, without recursion (trees are up to max_depth deep but can be wide)
+    order, stack = [], [root]
+    while stack:
+        k = stack.pop()
+        order.append(k)
+        if axis[k] >= 0:
+            for c in (left[k], right[k]):
+                if c >= 0:
+                    stack.append(c)
+    for k in reversed(order):
+        if axis[k] < 0:
+            made[k] = make_leaf([items[i].prim for i in leaf_items[left[k]:left[k] + right[k]]])
+        else:
+            made[k] = make_branch(int(axis[k]), float(split[k]), made.get(left[k]) if left[k] >= 0 else None,
+                                  made.get(right[k]) if right[k] >= 0 else None)
+    return lo, hi, made[root]
+
+
+def build_tree_arrays(items, max_depth=KD_DEFAULT_MAX_DEPTH, split_threshold=KD_DEFAULT_SPLIT_THRESHOLD,
+                      traversal_cost=0.0, intersection_cost=0.0):
+    """The same tree as flat arrays: (lo, hi, node_axis, node_split, node_left, node_right, leaf_items, root); leaf:
+    axis -1, left = first entry of leaf_items, right = count; leaf_items holds indices into `items`."""
     import ctypes as C
     from . import _lib
     if not items:
@@ -249,25 +274,10 @@ def build_tree(items, make_leaf, make_branch, max_depth=KD_DEFAULT_MAX_DEPTH, sp
         split = np.ctypeslib.as_array(out.node_split, (nn,)).copy()
         left = np.ctypeslib.as_array(out.node_left, (nn,)).copy()
         right = np.ctypeslib.as_array(out.node_right, (nn,)).copy()
+        out_leaf_items = out.n_leaf_items
         leaf_items = np.ctypeslib.as_array(out.leaf_items, (max(out.n_leaf_items, 1),)).copy()
         box = np.ctypeslib.as_array(out.aabb, (2 * n,)).copy()
         root = out.root
     finally:
         _lib.lib().nt_kdtree_free(C.byref(out))
-    made = {}
-    # children before parents, without recursion (trees are up to max_depth deep but can be wide)
-    order, stack = [], [root]
-    while stack:
-        k = stack.pop()
-        order.append(k)
-        if axis[k] >= 0:
-            for c in (left[k], right[k]):
-                if c >= 0:
-                    stack.append(c)
-    for k in reversed(order):
-        if axis[k] < 0:
-            made[k] = make_leaf([items[i].prim for i in leaf_items[left[k]:left[k] + right[k]]])
-        else:
-            made[k] = make_branch(int(axis[k]), float(split[k]), made.get(left[k]) if left[k] >= 0 else None,
-                                  made.get(right[k]) if right[k] >= 0 else None)
-    return box[:n].astype(f32), box[n:].astype(f32), made[root]
+    return box[:n].astype(f32), box[n:].astype(f32), axis, split, left, right, leaf_items[:out_leaf_items], root

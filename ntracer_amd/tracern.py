@@ -1151,6 +1151,7 @@ def build_kdtree(primitives, extra_threads=-1, **kwds):
     max_depth = int(kwds.pop("max_depth", builder.KD_DEFAULT_MAX_DEPTH))
     split_threshold = int(kwds.pop("split_threshold", builder.KD_DEFAULT_SPLIT_THRESHOLD))
     kwds.pop("update_primitives", None)
+    kwds_flat = bool(kwds.pop("_flat", False))
     traversal_cost = float(kwds.pop("traversal_cost", 0.0) or 0.0)
     intersection_cost = float(kwds.pop("intersection_cost", 0.0) or 0.0)
     if kwds:
@@ -1168,13 +1169,52 @@ def build_kdtree(primitives, extra_threads=-1, **kwds):
            if isinstance(p, TrianglePrototype)]
     other = [builder._Item(p.primitive, p.boundary.start._v, p.boundary.end._v) for p in protos if not isinstance(p, TrianglePrototype)]
     batches, loose = builder.group_batches(tri, BATCH_SIZE, TriangleBatch)
-    lo, hi, root = builder.build_tree(batches + loose + other, KDLeaf, KDBranch, max_depth, split_threshold,
-                                      traversal_cost, intersection_cost)
+    items = batches + loose + other
+    if kwds_flat:
+        return n, items, builder.build_tree_arrays(items, max_depth, split_threshold, traversal_cost, intersection_cost)
+    lo, hi, root = builder.build_tree(items, KDLeaf, KDBranch, max_depth, split_threshold, traversal_cost, intersection_cost)
     return AABB(n, lo, hi), root
 
 
 def build_composite_scene(primitives, extra_threads=-1, **kwds):
     """tracern.build_composite_scene(primitives[,extra_threads=-1,*,update_primitives=False]) -> CompositeScene
-    (ntracer_body.hpp:3335-3357)."""
-    boundary, root = build_kdtree(primitives, extra_threads, **kwds)
-    return CompositeScene(boundary, root)
+    (ntracer_body.hpp:3335-3357).  The tree goes from the native builder's arrays straight into the scene
+    description; KDBranch / KDLeaf objects are not made on the way."""
+    n, items, (lo, hi, axis, split, left, right, leaf_items, root) = build_kdtree(primitives, extra_threads, _flat=True, **kwds)
+    # primitive tables in item order, materials interned by value
+    mats, mat_ids = [], {}
+
+    def mat(m):
+        k = m._key()
+        if k not in mat_ids:
+            mat_ids[k] = len(mats)
+            mats.append(list(m.color) + list(m.specular) + [m.opacity, m.reflectivity, m.specular_intensity, m.specular_exp])
+        return mat_ids[k]
+
+    rl = n * n + n + 1
+    codes = np.zeros(len(items), np.int32)
+    batch_recs, batch_mats, tri_recs, tri_mats, solid_recs, solid_types, solid_mats = [], [], [], [], [], [], []
+    for k, it in enumerate(items):
+        p = it.prim
+        if isinstance(p, TriangleBatch):
+            codes[k] = (len(batch_recs) << 2) | _lib.KIND_BATCH
+            batch_recs.append([t._record() for t in p._tris])
+            batch_mats.append([mat(t.material) for t in p._tris])
+        elif isinstance(p, Triangle):
+            codes[k] = (len(tri_recs) << 2) | _lib.KIND_TRIANGLE
+            tri_recs.append(p._record())
+            tri_mats.append(mat(p.material))
+        else:
+            codes[k] = (len(solid_recs) << 2) | _lib.KIND_SOLID
+            solid_recs.append(np.concatenate([p.orientation._m.ravel(), p.inv_orientation._m.ravel(), p.position._v]))
+            solid_types.append(p.type)
+            solid_mats.append(mat(p.material))
+    d = dict(dimension=n, root=int(root), node_axis=np.asarray(axis, np.int32), node_split=np.asarray(split, f32),
+             node_left=np.asarray(left, np.int32), node_right=np.asarray(right, np.int32),
+             items=codes[np.asarray(leaf_items, np.int64)] if len(leaf_items) else np.zeros(0, np.int32),
+             batch_recs=np.asarray(batch_recs, f32).reshape(-1, BATCH_SIZE, rl), batch_mats=np.asarray(batch_mats, np.int32).reshape(-1, BATCH_SIZE),
+             tri_recs=np.asarray(tri_recs, f32).reshape(-1, rl), tri_mats=np.asarray(tri_mats, np.int32),
+             solid_recs=np.asarray(solid_recs, f32).reshape(-1, 2 * n * n + n), solid_types=np.asarray(solid_types, np.int32),
+             solid_mats=np.asarray(solid_mats, np.int32), materials=np.asarray(mats, f32).reshape(-1, 10),
+             aabb_start=np.asarray(lo, f32), aabb_end=np.asarray(hi, f32))
+    return CompositeScene.from_flat(n, d)
