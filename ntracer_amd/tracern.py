@@ -624,6 +624,7 @@ class CompositeScene(_SceneBase):
         if boundary.dimension != data.dimension:
             raise TypeError("boundary and data must have the same dimension")
         self._create(self._flatten(boundary, data))
+        self._root_obj = data
 
     @classmethod
     def from_flat(cls, dimension, flat):
@@ -752,6 +753,51 @@ class CompositeScene(_SceneBase):
         cam = self.get_camera()
         other._set_camera_arrays(cam._origin, cam._axes)
         return other
+
+    @property
+    def root(self):
+        """CompositeScene.root (ntracer_body.hpp:922-924): the k-d tree as KDBranch / KDLeaf objects over Triangle,
+        TriangleBatch and Solid objects.  Scenes made from flat arrays (build_composite_scene, from_flat) only
+        materialise these when asked."""
+        if getattr(self, "_root_obj", None) is not None:
+            return self._root_obj
+        f = self._flat
+        n = self._n
+        rl = n * n + n + 1
+        mats = [Material.__new__(Material) for _ in range(len(f["materials"]))]
+        for m, v in zip(mats, np.asarray(f["materials"], np.float64).reshape(-1, 10)):
+            m.color = Color(*v[0:3])
+            m.specular = Color(*v[3:6])
+            m.opacity, m.reflectivity, m.specular_intensity, m.specular_exp = (float(x) for x in v[6:10])
+
+        def tri(rec, mi):
+            rec = np.asarray(rec, f32)
+            return Triangle(rec[1 + n:1 + 2 * n], rec[1:1 + n], rec[1 + 2 * n:rl].reshape(n - 1, n), mats[int(mi)])
+
+        brecs = np.asarray(f["batch_recs"], f32).reshape(-1, BATCH_SIZE, rl)
+        bmats = np.asarray(f["batch_mats"], np.int64).reshape(-1, BATCH_SIZE)
+        batches = [TriangleBatch([tri(brecs[k, l], bmats[k, l]) for l in range(BATCH_SIZE)]) for k in range(len(brecs))]
+        trecs = np.asarray(f["tri_recs"], f32).reshape(-1, rl)
+        tris = [tri(trecs[k], f["tri_mats"][k]) for k in range(len(trecs))]
+        srecs = np.asarray(f["solid_recs"], f32).reshape(-1, 2 * n * n + n)
+        solids = [Solid(int(f["solid_types"][k]), srecs[k, 2 * n * n:], Matrix._wrap(srecs[k, :n * n].reshape(n, n)), mats[int(f["solid_mats"][k])])
+                  for k in range(len(srecs))]
+        tables = (batches, tris, solids)
+        axis, split, left, right, items = f["node_axis"], f["node_split"], f["node_left"], f["node_right"], f["items"]
+        made = {}
+        order, stack = [], [int(f["root"])] if int(f["root"]) >= 0 else []
+        while stack:
+            k = stack.pop()
+            order.append(k)
+            if axis[k] >= 0:
+                stack.extend(int(c) for c in (left[k], right[k]) if c >= 0)
+        for k in reversed(order):
+            if axis[k] < 0:
+                made[k] = KDLeaf([tables[int(it) & 3][int(it) >> 2] for it in items[int(left[k]):int(left[k]) + int(right[k])]])
+            else:
+                made[k] = KDBranch(int(axis[k]), float(split[k]), made.get(int(left[k])), made.get(int(right[k])))
+        self._root_obj = made.get(int(f["root"]))
+        return self._root_obj
 
     def _flat_description(self):
         """The flat arrays this scene was created from (layout of nt_scene_desc / tests/golden/*.npz)."""

@@ -121,6 +121,35 @@ def test_composite_scene_attribute_surface():
         sc.add_light(object())
 
 
+def test_scene_root_and_boundary_round_trip():
+    """scene.root / scene.boundary (ntracer_body.hpp:919-924): objects rebuilt from the flat description flatten back
+    to the same arrays, whether the scene came from flat arrays or from our builder."""
+    g = fx.load("feature3d")
+    flat = fx.flat_of(g)
+    sc = tracern.CompositeScene.from_flat(3, flat)
+    assert np.allclose(list(sc.boundary.start), flat["aabb_start"]) and np.allclose(list(sc.boundary.end), flat["aabb_end"])
+    again = tracern.CompositeScene._flatten(sc.boundary, sc.root)
+    for k in ("node_axis", "node_split", "batch_recs", "tri_recs", "solid_recs", "solid_types"):
+        assert np.array_equal(np.asarray(again[k]).ravel(), np.asarray(flat[k]).ravel()), k
+    assert len(again["items"]) == len(flat["items"])
+    nt = NTracer(3)
+    mat = ntracer_amd.Material((1, .5, .5))
+    sc2 = nt.build_composite_scene([nt.TrianglePrototype([(i, 0, 0), (i + 1, 0, 0), (i, 1, .2 * i)], mat) for i in range(9)])
+    leaves = []
+
+    def walk(nd):
+        if nd is None:
+            return
+        if isinstance(nd, tracern.KDLeaf):
+            leaves.append(nd)
+        else:
+            walk(nd.left)
+            walk(nd.right)
+
+    walk(sc2.root)
+    assert leaves and all(isinstance(p, tracern.TriangleBatch) for lf in leaves for p in lf)
+
+
 def test_wrapper_cache_and_scene_type_rules():
     assert NTracer(5) is NTracer(5)
     assert NTracer(5, force_generic=True) is not NTracer(5)
