@@ -95,6 +95,15 @@ class Vector(object):
         r = self.__eq__(o)
         return r if r is NotImplemented else not r
 
+    def set_c(self, index, value):
+        """Vector.set_c(index,value) -> a copy with one component replaced (ntracer_body.hpp:1998-2014)"""
+        index = int(index)
+        if index < 0 or index >= len(self._v):
+            raise IndexError("vector index out of range")
+        r = self._v.copy()
+        r[index] = f32(value)
+        return Vector._wrap(r)
+
     def square(self):
         return float(dot(self, self))
 
@@ -193,6 +202,10 @@ class Matrix(object):
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
+
+    def determinant(self):
+        """Matrix.determinant() (ntracer_body.hpp:2326-2330; the reference runs an fp32 LU, geometry.hpp:790-823)"""
+        return float(f32(np.linalg.det(self._m.astype(np.float64))))
 
     @property
     def values(self):

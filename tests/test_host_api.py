@@ -152,6 +152,18 @@ def test_scene_root_and_boundary_round_trip():
     assert leaves and all(isinstance(p, tracern.TriangleBatch) for lf in leaves for p in lf)
 
 
+def test_vector_set_c_and_matrix_determinant():
+    nt = NTracer(4)
+    v = nt.Vector(1, 2, 3, 4)
+    w = v.set_c(2, 9.5)
+    assert list(w) == [1, 2, 9.5, 4] and list(v) == [1, 2, 3, 4]
+    with pytest.raises(IndexError):
+        v.set_c(4, 0)
+    m = nt.Matrix([[2, 0, 0, 0], [0, 3, 0, 0], [0, 0, 4, 0], [1, 1, 1, 5]])
+    assert abs(m.determinant() - 120) < 1e-4
+    assert abs(nt.Matrix.rotation(nt.Vector.axis(0), nt.Vector.axis(1), .7).determinant() - 1) < 1e-6
+
+
 def test_wrapper_cache_and_scene_type_rules():
     assert NTracer(5) is NTracer(5)
     assert NTracer(5, force_generic=True) is not NTracer(5)
