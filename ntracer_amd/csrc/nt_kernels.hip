@@ -430,30 +430,105 @@ __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir
     }
 }
 
-// One pixel of BoxScene from the unnormalised direction `dir` (|dir|^2 = sq), sx / sy as in the ray source.
+// Which rays need the exact evaluation at all?  Everything below works on the UNNORMALISED direction v
+// (p_j(tau) = o_j + v_j*tau; the reference's dist is tau*|v|), with reciprocals from v_rcp_f32, and sorts a lane
+// that may hit into one of three classes.  m = 1e-4*(1 + max|o_j|) is ~100x the sum of ROUNDING_FUZZ and every
+// rounding error involved (the reference's p_j carry ~(n+6)*2^-24*(1+|o_j|), the ones here ~2^-22*(1+|o_j|)).
+//   miss      the ray (tau > 0) stays outside the cube grown to 1+m.  Every point the reference accepts has
+//             |p_i| = 1, |p_j| <= 1+FUZZ at a dist > 0, so the reference finds no face either.
+//   hit at K  K = the entry face reached last, at tau_K; tau_K is clearly positive; at tau_K every other
+//             coordinate is inside 1-m/2 (the reference's test for K passes); and every other entry plane is
+//             crossed while p_K is still outside 1+m ((tau_K - tau_i)*|v_K| > m), so no face before K in the
+//             reference's ascending order can pass its j = K check.  The reference returns face K: shade |d_K|.
+//   unclear   anything else (edges, grazing rays, origins on or inside the cube, NaN): the wave takes the exact,
+//             reference-ordered evaluation in box_color.
+// x = the component the colour is made of: v_K for a hit, v_0 for the background.
 template <int N>
+__device__ __forceinline__ void box_classify(const float (&o)[N], const float (&v)[N], float m, bool maybe, bool &hit, bool &unclear,
+                                             float &x) {
+    float tn = -INFINITY, tn2 = -INFINITY, vK = 0.0f;      // last and second-to-last entry, unit cube
+    float tnp = -INFINITY, tfp = INFINITY;                 // last entry / first exit, cube grown by m
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float inv = __builtin_amdgcn_rcpf(v[j]);
+        const float a = (-1.0f - o[j]) * inv, b = (1.0f - o[j]) * inv;
+        const float nr = fminf(a, b), fr = fmaxf(a, b);     // a NaN (v_j = 0 and o_j = -+1, or 0*inf) drops out
+        const float w = m * fabsf(inv);
+        tnp = fmaxf(tnp, nr - w);
+        tfp = fminf(tfp, fr + w);
+        const bool later = nr > tn;
+        tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);
+        vK = later ? v[j] : vK;
+        tn = fmaxf(tn, nr);
+    }
+    const bool miss = tnp > tfp || tfp < 0.0f;
+    const float c = 1.0f - m;
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) sum = sum + fmaxf(fabsf(fmaf(v[j], tn, o[j])), c);
+    // face K itself contributes 1 - c = m; the others nothing unless they are within m of their planes
+    const bool inside = sum - (float)N * c <= 1.5f * m;
+    const bool sole = (tn - tn2) * fabsf(vK) > m;
+    const bool front = tn > 1e-3f && tn < 1e30f;
+    hit = maybe && !miss && inside && sole && front;
+    unclear = maybe && !miss && !hit;
+    x = hit ? vK : v[0];
+}
+
+// One pixel of BoxScene from the unnormalised direction `dir` (|dir|^2 = sq), sx / sy as in the ray source.
+// PLAIN: the format is known to be plain_rgb with at most 10 bits per channel (the launcher checks).
+template <int N, bool PLAIN>
 __device__ __forceinline__ void box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
-                                          const float (&dots)[4], float sx, float sy) {
-    const float len = sqrtf(sq);
+                                          const float (&dots)[4], float sx, float sy, float margin) {
     const bool maybe = box_may_hit(N, dots, sx, sy, sq);
     float r, g, b;
-    if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) {
-        const float in = dir[0] / len;
-        if (plain_rgb(tg)) {
-            // (i,i,i) or (0,-i,-i): one magnitude, one quantisation
-            const uint32_t q = plain_quantize(tg, fabsf(in));
-            emit_plain(tg, pr, in > 0.0f ? q : 0u, q);
-            return;
+    bool hit = false, unclear = false;
+    float x = dir[0];
+#ifndef NT_EXP_NOCLASSIFY
+    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) box_classify<N>(org, dir, margin, maybe, hit, unclear, x);
+#else
+    unclear = maybe;
+#endif
+    if (__builtin_amdgcn_ballot_w64(unclear) == 0ull) {
+        // every lane's colour is |x|/len times (1,.5,.5) (hit) or (1,1,1) / (0,1,1) (background, by the sign of x)
+        if (PLAIN || (plain_rgb(tg) && tg.plain_bits <= 10u)) {
+            // Only round(value * maxval) is stored.  |x| * rsq(sq) is within 3*2^-23 of the reference's twice-rounded
+            // |x/len| (v_rsq_f32: 1 ulp; two multiplications here; sqrt and division there), so whenever
+            // t = that * maxval keeps 2^-20*(1+t) clear of every k + 1/2 the two round to the same integer: no
+            // sqrt, no division.  (A hit also stores round(t/2).)  A wave with a lane inside a guard band (a few
+            // per cent of them at 8 bits), or with a NaN / infinity, takes the exact division below.
+            const float maxv = (float)tg.plain_maxval;
+            const float t = (fabsf(x) * __builtin_amdgcn_rsqf(sq)) * maxv;
+            const float tgb = hit ? t * 0.5f : t;
+            const bool clear_gb = fabsf(__builtin_amdgcn_fractf(tgb) - 0.5f) > fmaf(tgb, 0x1p-20f, 0x1p-20f);
+            const bool clear_r = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-20f, 0x1p-20f);
+            if (__builtin_amdgcn_ballot_w64(!(clear_gb && (clear_r || !hit))) == 0ull) {
+                uint32_t qgb = (uint32_t)(tgb + 0.5f), qr = (uint32_t)(t + 0.5f);
+                qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;    // the value may round to just above 1: clamped
+                qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
+                emit_plain(tg, pr, (hit || x > 0.0f) ? qr : 0u, qgb);
+                return;
+            }
         }
-        box_background(in, r, g, b);
+        const float in = x / sqrtf(sq);
+        if (hit) {
+            // sine = d_K * (-sign d_K) <= 0, shade = -sine (tracer.hpp:105-107)
+            const float shade = fabsf(in);
+            r = shade * 1.0f;
+            g = shade * 0.5f;
+            b = shade * 0.5f;
+        } else {
+            box_background(in, r, g, b);
+        }
     } else {
+        const float len = sqrtf(sq);
 #pragma unroll
         for (int j = 0; j < N; ++j) dir[j] = dir[j] / len;
         box_color<N>(org, dir, maybe, r, g, b);
-        if (plain_rgb(tg)) {
-            emit_plain(tg, pr, plain_quantize(tg, r), plain_quantize(tg, g));       // g == b
-            return;
-        }
+    }
+    if (PLAIN || plain_rgb(tg)) {
+        emit_plain(tg, pr, plain_quantize(tg, r), plain_quantize(tg, g));       // g == b
+        return;
     }
     emit_pixel(tg, pr, r, g, b);
 }
@@ -463,11 +538,15 @@ __device__ __forceinline__ void box_pixel(const NtTarget &tg, const PixelRef &pr
 // the instructions off the path most rays take.
 // (n <= 8; beyond that the extra registers cost more than the shared work saves: measured on n = 10)
 template <int N> struct BoxRows { static constexpr int value = N <= 8 ? 4 : 1; };
-template <int N>
+template <int N, bool PLAIN>
 __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg) {
     const int tid = (int)threadIdx.x;
     float org[N], right[N], up[N], fwd[N], dir[N];
     load_camera<N>(cam, org, right, up, fwd);
+    float margin = fabsf(org[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
+    margin = 1e-4f * (1.0f + margin);
     float dots[4];
     if (cam.buf) {
         const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
@@ -475,7 +554,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
     } else {
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
     }
-    if (tg.colors_out || BoxRows<N>::value == 1) {
+    if ((!PLAIN && tg.colors_out) || BoxRows<N>::value == 1) {
         // one pixel per lane: probe mode (listed pixels), and n > 8
         const PixelRef pr = locate_pixel<64, 4>(tg, tid & 63, tid >> 6, tid);
         if (!pr.valid) return;
@@ -487,7 +566,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         float sq = dir[0] * dir[0];
 #pragma unroll
         for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-        box_pixel<N>(tg, pr, org, dir, sq, dots, sx, sy);
+        box_pixel<N, PLAIN>(tg, pr, org, dir, sq, dots, sx, sy, margin);
         return;
     }
     const int x = (int)blockIdx.x * 64 + (tid & 63);
@@ -519,7 +598,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         float sq = dir[0] * dir[0];
 #pragma unroll
         for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-        box_pixel<N>(tg, pr, org, dir, sq, dots, sx, sy);
+        box_pixel<N, PLAIN>(tg, pr, org, dir, sq, dots, sx, sy, margin);
     }
 }
 
@@ -2826,7 +2905,11 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];
     dim3 grid;
     grid_for(tg, 64, tg.colors_out ? 4 : 4 * BoxRows<N>::value, li.nframes, grid);
-    hipLaunchKernelGGL(box_kernel<N>, grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+    // the common packed-RGB formats get the kernel with the format tests compiled out
+    if (tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4 && !tg.colors_out)
+        hipLaunchKernelGGL((box_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+    else
+        hipLaunchKernelGGL((box_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
     return 0;
 }
 

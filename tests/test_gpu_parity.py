@@ -83,6 +83,61 @@ def test_box_full_frame_bytes_equal_oracle(n, w, h):
         assert np.array_equal(img, ref)
 
 
+def _stress_cameras(n, rng):
+    """orientations x origins chosen to land rays on edges, faces' planes, the inside, grazing directions"""
+    cams = []
+    eye = np.eye(n, dtype=np.float32)
+    for k in range(10):
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        if k == 0:
+            q = eye.copy()                                   # axis-aligned: direction components exactly 0
+        elif k == 1:
+            q = eye + 1e-7 * rng.standard_normal((n, n))     # almost axis-aligned: grazing rays
+        elif k == 2:
+            q = eye[rng.permutation(n)]
+        q = np.ascontiguousarray(q, np.float32)
+        for dist in (0.3, 1.0, 1.0000001, 1.7, 3.0, 9.0, 60.0):
+            back = -q[2] * np.float32(dist)                  # look at the centre from `dist` away ...
+            cams.append((back.astype(np.float32), q))
+            off = back + np.float32(0.4) * q[0] + np.float32(0.25) * q[1]          # ... and off-centre
+            cams.append((off.astype(np.float32), q))
+        o = np.zeros(n, np.float32)
+        o[:3] = (-1.0, 0.3, -2.5)                            # origin exactly on the plane of a face
+        cams.append((o, q))
+        o = o.copy()
+        o[0] = 1.0
+        o[min(3, n - 1)] = 1.0                               # on two planes at once
+        cams.append((o, q))
+    return cams
+
+
+@pytest.mark.parametrize("n", [3, 4, 6, 8, 10])
+def test_box_stress_cameras_bytes_and_floats_equal_oracle(n):
+    """The BoxScene kernel sorts rays into clear misses, clear hits and unclear ones, and only the last get the
+    reference-ordered evaluation; quantised formats also skip the sqrt and the division away from rounding
+    boundaries.  Every shortcut is guarded, so whole frames must still equal the oracle byte for byte: RGBX8
+    (the specialised kernel), RGB565-like 5-bit channels, 16-bit channels and fp32 channels (the general one)."""
+    rng = np.random.default_rng(1234 + n)
+    w, h = 320, 72
+    formats = [fx.RGBX8,
+               [(5, 1, 0, 0), (6, 0, 1, 0), (5, 0, 0, 1)],
+               [(16, 0, 0, 1), (16, 0, 1, 0), (16, 1, 0, 0)],
+               [(32, 1, 0, 0, 0, True), (32, 0, 1, 0, 0, True), (32, 0, 0, 1, 0, True)]]
+    sc = tracern.BoxScene(n)
+    for k, (origin, axes) in enumerate(_stress_cameras(n, rng)):
+        sc._set_camera_arrays(origin, axes)
+        osc = ob.OracleScene(n, origin, axes)
+        chans = formats[k % len(formats)] if k % 3 else fx.RGBX8
+        img = render_host(sc, fmt_of(w, h, chans))
+        ref = osc.render(w, h, chans, threads=7)
+        assert np.array_equal(img, ref), (n, k, int((img != ref).sum()))
+        if k % 5 == 0:
+            xs = rng.integers(0, w, 2000)
+            ys = rng.integers(0, h, 2000)
+            got = sc.colors_at(xs, ys, w, h)
+            assert np.array_equal(got.view(np.uint32), osc.colors_at(xs, ys, w, h).view(np.uint32)), (n, k)
+
+
 def test_box10_4096_both_kernels_properties_and_samples(monkeypatch):
     """config 5 at full size, 4096x4096, through the compile-time-N kernel (default for n <= 10) and through the
     run-time-n kernel (NTRACER_FORCE_VAR; the only one for n > 10): identical frames.  Oracle on sampled rows; at
