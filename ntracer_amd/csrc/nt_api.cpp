@@ -80,6 +80,7 @@ struct DeviceState {
     DevBuf framebuffer, cams, probes, stats, counter;
     DevBuf hits;                         // primary-hit records between the two passes of a lit render
     DevBuf numer;                        // packet kernel: -(N.o + d) per (frame, simplex)
+    DevBuf cull;                         // BoxScene: row culling bits
     struct TileOrder { int tx = 0, ty = 0; DevBuf buf; };
     std::vector<std::unique_ptr<TileOrder>> tile_orders;   // packet kernel: tiles sorted centre-out, per tile grid
     int cu_count = 0;
@@ -507,6 +508,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     li.hit_frames = 0;
     li.numer_buf = nullptr;
     li.numer_frames = 0;
+    li.cull_buf = nullptr;
     if (const char *kc = getenv("NTRACER_COMPOSITE_KERNEL")) li.kernel_choice = atoi(kc);
     int r;
     if (s->composite) {
@@ -592,6 +594,13 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         }
         r = nt_launch_composite(li, cam, c, tg);
     } else {
+        const char *ec = getenv("NTRACER_BOX_CULL");
+        if (!tg.colors_out && !(ec && atoi(ec) == 0)) {
+            // one bit per 64-pixel stretch of a row: can any of its rays reach the cube? (box_cull_kernel)
+            const size_t words = (size_t)(((tg.width + 63) / 64 + 31) / 32);
+            if (int e = ds->cull.ensure((size_t)job.nframes * tg.row_count * words * sizeof(uint32_t))) return e;
+            li.cull_buf = (uint32_t *)ds->cull.p;
+        }
         r = nt_launch_box(li, cam, tg);
     }
     if (r) return fail(r == -2 ? NT_E_UNSUPPORTED : NT_E_DEVICE, "%s", nt_launch_error());
@@ -766,7 +775,7 @@ void nt_scene_destroy(nt_scene_t *s) {
         (void)hipDeviceSynchronize();
         for (DevBuf *b : {&ds->nodes, &ds->items, &ds->batch_recs, &ds->batch_mats, &ds->tri_recs, &ds->tri_mats, &ds->solid_recs,
                           &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams, &ds->counter,
-                          &ds->probes, &ds->stats, &ds->hits, &ds->numer})
+                          &ds->probes, &ds->stats, &ds->hits, &ds->numer, &ds->cull})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
         for (auto &t : ds->tile_orders) t->buf.release();

@@ -51,6 +51,10 @@ struct NtTarget {
     // two-pass renders of lit scenes: primary hits found by the packet kernel, [frame][row][x] records of 16 bytes
     // (dist, item, lane, -); nullptr otherwise
     const void *hits;
+    // BoxScene: one bit per (frame, owned row, 64-pixel column) -- 0: no ray of that stretch can reach the cube
+    // (box_cull_kernel); [frame][row][cull_words] dwords, or nullptr
+    const uint32_t *cull;
+    int cull_words;
 };
 
 // Camera rows used by the ray source (camera.hpp:40-45): origin, right, up, forward.
@@ -126,6 +130,7 @@ struct NtLaunchInfo {
     int hit_frames;
     float *numer_buf;         // scratch for the packet kernel's plane numerators: numer_frames * n_batches * 4 floats
     int numer_frames;
+    uint32_t *cull_buf;       // BoxScene: scratch for the row culling bits, nframes * row_count * ceil(ceil(width/64)/32) dwords (or nullptr)
 };
 
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);

@@ -472,6 +472,9 @@ __device__ __forceinline__ void box_classify(const float (&o)[N], const float (&
     const bool front = tn > 1e-3f && tn < 1e30f;
     hit = maybe && !miss && inside && sole && front;
     unclear = maybe && !miss && !hit;
+#ifdef NT_EXP_NOUNCLEAR
+    unclear = false;
+#endif
     x = hit ? vK : v[0];
 }
 
@@ -479,8 +482,9 @@ __device__ __forceinline__ void box_classify(const float (&o)[N], const float (&
 // PLAIN: the format is known to be plain_rgb with at most 10 bits per channel (the launcher checks).
 template <int N, bool PLAIN>
 __device__ __forceinline__ void box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
-                                          const float (&dots)[4], float sx, float sy, float margin) {
-    const bool maybe = box_may_hit(N, dots, sx, sy, sq);
+                                          const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true) {
+    // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
+    const bool maybe = rowhit && box_may_hit(N, dots, sx, sy, sq);
     float r, g, b;
     bool hit = false, unclear = false;
     float x = dir[0];
@@ -537,7 +541,10 @@ __device__ __forceinline__ void box_pixel(const NtTarget &tg, const PixelRef &pr
 // consecutive pixels of a row at a time): forward + right*sx is the same for all of them, which takes a tenth of
 // the instructions off the path most rays take.
 // (n <= 8; beyond that the extra registers cost more than the shared work saves: measured on n = 10)
-template <int N> struct BoxRows { static constexpr int value = N <= 8 ? 4 : 1; };
+#ifndef NT_BOXROWS
+#define NT_BOXROWS 8
+#endif
+template <int N> struct BoxRows { static constexpr int value = N <= 8 ? NT_BOXROWS : 1; };
 template <int N, bool PLAIN>
 __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg) {
     const int tid = (int)threadIdx.x;
@@ -575,10 +582,23 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
     float base[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
-    const int row0 = ((int)blockIdx.y * 4 + (tid >> 6)) * BoxRows<N>::value;
+    // the wave's number as a scalar: everything that depends on the row alone stays on the scalar unit
+    const int row0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * BoxRows<N>::value;
+    // the culling bits of the wave's rows, fetched together ahead of the loop (bit rr: row0 + rr may reach the cube)
+    uint32_t rowmask = ~0u;
+    if (tg.cull) {
+        rowmask = 0u;
+#pragma unroll
+        for (int rr = 0; rr < BoxRows<N>::value; ++rr) {
+            const int row = row0 + rr < tg.row_count ? row0 + rr : tg.row_count - 1;
+            const uint32_t bits = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 5)];
+            rowmask |= ((bits >> (blockIdx.x & 31)) & 1u) << rr;
+        }
+    }
     for (int rr = 0; rr < BoxRows<N>::value; ++rr) {
         const int row = row0 + rr;                      // relative to row_begin; the same for the whole wave
         if (row >= tg.row_count) return;
+        const bool rowhit = (rowmask >> rr) & 1u;
         const int orow = tg.row_begin + row;
         int y = orow;
         if (tg.band_world > 1) {
@@ -598,7 +618,63 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         float sq = dir[0] * dir[0];
 #pragma unroll
         for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-        box_pixel<N, PLAIN>(tg, pr, org, dir, sq, dots, sx, sy, margin);
+        box_pixel<N, PLAIN>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit);
+    }
+}
+
+// Which 64-pixel stretches of which rows can reach the cube at all?  One thread per stretch: the rays of a stretch
+// are v = vc + right*e with vc the direction through its middle and |e| <= 32*fovI, so a ray that comes within
+// h = 1 + 2m + 1e-3 of the cube in every coordinate at some tau > 0 (every ray the reference could call a hit
+// does, see box_classify) satisfies, with g_j = 32*fovI*|right_j| (+1e-6 for the rounding of v itself),
+//     (vc_j + g_j)*tau >= -h - o_j     and     (vc_j - g_j)*tau <= h - o_j         for every j:
+// 2n half-lines in tau.  An empty intersection clears the stretch's bit, and box_kernel then paints background
+// there without looking further.  Convexity makes this sharp: the bits left set are the stretches within half a
+// stretch of the cube's silhouette.  Reciprocals are approximate (v_rcp_f32); the 1e-3 in h is ~1000x their error.
+template <int N>
+__global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarget tg, uint32_t *out, int words, int ncols) {
+    float org[N], right[N], up[N], fwd[N];
+    load_camera<N>(cam, org, right, up, fwd);
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int rw = i >> 5;                               // (row, word): the same for a half-wave
+    const int word = rw % words, row = rw / words;
+    const int col = word * 32 + (i & 31);
+    bool keep = false;
+    if (row < tg.row_count && col < ncols) {
+        const int orow = tg.row_begin + row;
+        int y = orow;
+        if (tg.band_world > 1) {
+            const int band = orow / tg.band_rows;
+            y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+        }
+        float omax = fabsf(org[0]);
+#pragma unroll
+        for (int j = 1; j < N; ++j) omax = fmaxf(omax, fabsf(org[j]));
+        const float h = 1.0f + 2e-4f * (1.0f + omax) + 1e-3f;
+        const float sxc = tg.fovI * (((float)(col * 64) + 31.5f) - tg.half_w);
+        const float sy = tg.fovI * ((float)y - tg.half_h);
+        const float spread = 32.0f * tg.fovI;
+        float tlo = 0.0f, thi = INFINITY;
+        bool dead = false;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float vc = (fwd[j] + right[j] * sxc) - up[j] * sy;
+            const float g = fmaf(spread, fabsf(right[j]), 1e-6f);
+            const float pa = vc + g, qa = -h - org[j];
+            const float pb = vc - g, qb = h - org[j];
+            const float ra = qa * __builtin_amdgcn_rcpf(pa), rb = qb * __builtin_amdgcn_rcpf(pb);
+            if (pa > 0.0f) tlo = fmaxf(tlo, ra);
+            else if (pa < 0.0f) thi = fminf(thi, ra);
+            else if (pa == 0.0f && qa > 0.0f) dead = true;
+            if (pb > 0.0f) thi = fminf(thi, rb);
+            else if (pb < 0.0f) tlo = fmaxf(tlo, rb);
+            else if (pb == 0.0f && qb < 0.0f) dead = true;
+        }
+        keep = !(dead || tlo > thi);                    // a NaN keeps the stretch
+    }
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
+    if (row < tg.row_count && (threadIdx.x & 31) == 0) {
+        const size_t at = ((size_t)blockIdx.z * tg.row_count + row) * words + word;
+        out[at] = (threadIdx.x & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
     }
 }
 
@@ -2897,14 +2973,25 @@ void grid_for(const NtTarget &tg, int bw, int bh, int nframes, dim3 &grid) {
 }
 
 template <int N>
-int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg) {
+int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg_in) {
     NtCameraFixed cf;
     cf.buf = cam.buf;
     for (int k = 0; k < 4; ++k) cf.odots[k] = cam.odots[k];
     cf.n = N;
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];
+    NtTarget tg = tg_in;
     dim3 grid;
     grid_for(tg, 64, tg.colors_out ? 4 : 4 * BoxRows<N>::value, li.nframes, grid);
+    tg.cull = nullptr;
+    tg.cull_words = 0;
+    if (li.cull_buf && !tg.colors_out && BoxRows<N>::value > 1) {
+        const int ncols = (tg.width + 63) / 64, words = (ncols + 31) / 32;
+        const long long threads = (long long)tg.row_count * words * 32;
+        hipLaunchKernelGGL(box_cull_kernel<N>, dim3((unsigned)((threads + 255) / 256), 1, (unsigned)li.nframes), dim3(256), 0,
+                           (hipStream_t)li.stream, cf, tg, li.cull_buf, words, ncols);
+        tg.cull = li.cull_buf;
+        tg.cull_words = words;
+    }
     // the common packed-RGB formats get the kernel with the format tests compiled out
     if (tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4 && !tg.colors_out)
         hipLaunchKernelGGL((box_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
