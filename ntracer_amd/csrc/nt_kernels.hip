@@ -576,14 +576,33 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         box_pixel<N, PLAIN>(tg, pr, org, dir, sq, dots, sx, sy, margin);
         return;
     }
-    const int x = (int)blockIdx.x * 64 + (tid & 63);
-    if (x >= tg.width) return;
+    // the wave's number as a scalar: everything that depends on the row alone stays on the scalar unit
+    const int row0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * BoxRows<N>::value;
+    // sy and up[0]*sy of the wave's rows, one row per lane: the loop reads them back with v_readlane (computed while
+    // every lane is still active -- lanes past the right edge leave next)
+    float v_sy, v_us0;
+    {
+        const int lorow = tg.row_begin + row0 + (tid & 63);
+        int ly = lorow;
+        if (tg.band_world > 1) {
+            const int band = lorow / tg.band_rows;
+            ly = (band * tg.band_world + tg.band_rank) * tg.band_rows + (lorow - band * tg.band_rows);
+        }
+        v_sy = tg.fovI * ((float)ly - tg.half_h);
+        v_us0 = up[0] * v_sy;
+    }
+    int x = (int)blockIdx.x * 64 + (tid & 63);
+    if (PLAIN) {
+        // lanes past the right edge redo the last pixel (the same dword, the same value) rather than leave: the
+        // v_readlane above needs lanes 0..7 alive whatever the width
+        x = x < tg.width ? x : tg.width - 1;
+    } else if (x >= tg.width) {
+        return;
+    }
     const float sx = tg.fovI * ((float)x - tg.half_w);
     float base[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
-    // the wave's number as a scalar: everything that depends on the row alone stays on the scalar unit
-    const int row0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * BoxRows<N>::value;
     // the culling bits of the wave's rows, fetched together ahead of the loop (bit rr: row0 + rr may reach the cube)
     uint32_t rowmask = ~0u;
     if (tg.cull) {
@@ -594,6 +613,26 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
             const uint32_t bits = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 5)];
             rowmask |= ((bits >> (blockIdx.x & 31)) & 1u) << rr;
         }
+    }
+    // Background rows of quantised formats need |dir|^2 only to ~2^-19 (see the guard below): as a quadratic in sy,
+    //   |base - up*sy|^2 = base.base - 2*sy*(base.up) + sy^2*(up.up),
+    // it costs two fma per row instead of the N-1 other components and their squares.  Its absolute error is
+    // ~2.7n*2^-24*(base.base + sy^2 up.up), and that is relative to the result as long as the cross term cannot
+    // cancel the squares: lanes check (base.up)^2 <= base.base*up.up/16 (any sane camera: up is orthogonal to
+    // forward and right), and a wave with a lane that fails it never takes the shortcut.
+    const bool quant = PLAIN;                     // the launcher picks PLAIN for exactly the formats this applies to
+    float bb = 0.0f, m2bu = 0.0f, uu = 0.0f;
+    bool fastsq = false;
+    if (quant) {
+        float bu = 0.0f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            bb = fmaf(base[j], base[j], bb);
+            bu = fmaf(base[j], up[j], bu);
+            uu = fmaf(up[j], up[j], uu);
+        }
+        m2bu = -2.0f * bu;
+        fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
     }
     for (int rr = 0; rr < BoxRows<N>::value; ++rr) {
         const int row = row0 + rr;                      // relative to row_begin; the same for the whole wave
@@ -612,6 +651,24 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         pr.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
         pr.hit_index = 0;
         pr.valid = true;
+        if (quant && fastsq) {
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+            const float us0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_us0), rr));
+            const float d0 = base[0] - us0;                           // dir[0], bit for bit
+            const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
+            if (!rowhit || __builtin_amdgcn_ballot_w64(box_may_hit(N, dots, sx, sy, sqa)) == 0ull) {
+                // background: round(|dir[0]|/len * maxval), as in box_pixel, with the guard widened for sqa:
+                // sqa is within (3.7n+4)*2^-24 of the reference's sum, so t is within ~22*2^-24 < 2^-19.4 of its value (n <= 8); guard 2^-18
+                const float t = (fabsf(d0) * __builtin_amdgcn_rsqf(sqa)) * (float)tg.plain_maxval;
+                const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);
+                if (__builtin_amdgcn_ballot_w64(!clear) == 0ull) {
+                    uint32_t q = (uint32_t)(t + 0.5f);
+                    q = q < tg.plain_maxval ? q : tg.plain_maxval;
+                    emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
+                    continue;
+                }
+            }
+        }
         const float sy = tg.fovI * ((float)y - tg.half_h);
 #pragma unroll
         for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
