@@ -55,6 +55,9 @@ struct NtTarget {
     // (box_cull_kernel); [frame][row][cull_words] dwords, or nullptr
     const uint32_t *cull;
     int cull_words;
+    // same shape: box_kernel sets the bit of a stretch it leaves to box_redo_kernel (a lane needed the reference's
+    // own face-by-face arithmetic); cleared by box_cull_kernel
+    uint32_t *redo;
 };
 
 // Camera rows used by the ray source (camera.hpp:40-45): origin, right, up, forward.
@@ -130,7 +133,7 @@ struct NtLaunchInfo {
     int hit_frames;
     float *numer_buf;         // scratch for the packet kernel's plane numerators: numer_frames * n_batches * 4 floats
     int numer_frames;
-    uint32_t *cull_buf;       // BoxScene: scratch for the row culling bits, nframes * row_count * ceil(ceil(width/64)/32) dwords (or nullptr)
+    uint32_t *cull_buf;       // BoxScene: scratch for the row culling bits, 2 * nframes * row_count * ceil(ceil(width/64)/32) dwords: culling bits, then redo bits (or nullptr)
 };
 
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);

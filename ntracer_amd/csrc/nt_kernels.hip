@@ -445,14 +445,17 @@ __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir
 // x = the component the colour is made of: v_K for a hit, v_0 for the background.
 template <int N>
 __device__ __forceinline__ void box_classify(const float (&o)[N], const float (&v)[N], float m, bool maybe, bool &hit, bool &unclear,
-                                             float &x) {
-    float tn = -INFINITY, tn2 = -INFINITY, vK = 0.0f;      // last and second-to-last entry, unit cube
+                                             float &x, float (&near)[N], float &tn, float &vK) {
+    float tn2 = -INFINITY;                                 // tn, tn2: last and second-to-last entry, unit cube
+    tn = -INFINITY;
+    vK = 0.0f;
     float tnp = -INFINITY, tfp = INFINITY;                 // last entry / first exit, cube grown by m
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const float inv = __builtin_amdgcn_rcpf(v[j]);
         const float a = (-1.0f - o[j]) * inv, b = (1.0f - o[j]) * inv;
         const float nr = fminf(a, b), fr = fmaxf(a, b);     // a NaN (v_j = 0 and o_j = -+1, or 0*inf) drops out
+        near[j] = nr;
         const float w = m * fabsf(inv);
         tnp = fmaxf(tnp, nr - w);
         tfp = fminf(tfp, fr + w);
@@ -478,10 +481,67 @@ __device__ __forceinline__ void box_classify(const float (&o)[N], const float (&
     x = hit ? vK : v[0];
 }
 
+// The unclear lanes of a wave, resolved with the reference's own arithmetic -- but only the part of it that can
+// matter.  With near[], tn, vK from box_classify (approximate; the margins absorb that):
+//   T = { i : (tn - near_i)*|v_K| <= m }   the faces that can still be the reference's answer: any other face is
+//       entered while p_K is outside 1+m and fails its j = K check (box_classify);
+//   C = { j : |p_j(tn)| + |v_j|*m/|v_K| > 1 - m/2 }   the coordinates whose test some face of T could fail: every
+//       face of T is entered within m/|v_K| of tn, so a coordinate outside C is inside 1-m/2 at all of them.
+//       T is a subset of C (p_i(tn) is within |v_i|*m/|v_K| of +-1 for i in T).
+// The faces of T are tried in ascending order exactly as hypercube_intersects does (tracer.hpp:126-152): dist from the
+// IEEE quotient, then d_j*dist + o_j against 1+FUZZ for the j in C; d_j = v_j/len is computed for the axes of C only.
+// A lane whose tn is not a usable number gets T = C = everything, i.e. the reference's full loop.
+template <int N>
+__device__ __forceinline__ void box_resolve(const float (&o)[N], const float (&v)[N], float len, float m, const float (&near)[N], float tn,
+                                            float vK, bool unclear, bool &hit, float &x) {
+    const float aK = fabsf(vK);
+    const float slack = m * __builtin_amdgcn_rcpf(aK), lim = 1.0f - 0.5f * m;
+    bool inT[N], inC[N];
+    float d[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const bool early = (tn - near[j]) * aK > m;                                     // false for a NaN
+        const bool robust = fmaf(fabsf(v[j]), slack, fabsf(fmaf(v[j], tn, o[j]))) <= lim;  // false for a NaN
+        inT[j] = unclear && !early;
+        inC[j] = unclear && !(robust && early);
+        d[j] = 0.0f;
+        if (__builtin_amdgcn_ballot_w64(inC[j]) != 0ull) d[j] = v[j] / len;
+    }
+    bool done = false, found = false;
+    float xs = v[0];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const bool cand = inT[i] && !done;
+        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
+            const float di = d[i];
+            const float dist = ((di < 0.0f ? 1.0f : -1.0f) - o[i]) / di;
+            bool ok = cand && di != 0.0f && dist > 0.0f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (j != i) {
+                    const float p = d[j] * dist + o[j];
+                    ok = ok && !(inC[j] && fabsf(p) > (1.0f + NT_FUZZ));
+                }
+            }
+            if (ok) {
+                done = true;
+                // `if(dist >= cutoff) return 0` with cutoff = FLT_MAX (tracer.hpp:142): a miss
+                if (!(dist >= FLT_MAX)) { found = true; xs = v[i]; }
+            }
+        }
+    }
+    if (unclear) {
+        hit = found;
+        x = xs;
+    }
+}
+
 // One pixel of BoxScene from the unnormalised direction `dir` (|dir|^2 = sq), sx / sy as in the ray source.
 // PLAIN: the format is known to be plain_rgb with at most 10 bits per channel (the launcher checks).
-template <int N, bool PLAIN>
-__device__ __forceinline__ void box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
+// DEFER: a wave with an unclear lane writes nothing and returns false (the caller hands the stretch to box_redo_kernel),
+// which keeps the resolving code -- and its registers -- out of the kernel every other wave runs.
+template <int N, bool PLAIN, bool DEFER = false>
+__device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
                                           const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true) {
     // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
     const bool maybe = rowhit && box_may_hit(N, dots, sx, sy, sq);
@@ -489,7 +549,19 @@ __device__ __forceinline__ void box_pixel(const NtTarget &tg, const PixelRef &pr
     bool hit = false, unclear = false;
     float x = dir[0];
 #ifndef NT_EXP_NOCLASSIFY
-    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) box_classify<N>(org, dir, margin, maybe, hit, unclear, x);
+    float near[N], tn = 0.0f, vK = 0.0f;
+    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) box_classify<N>(org, dir, margin, maybe, hit, unclear, x, near, tn, vK);
+    // unclear lanes: the reference's arithmetic on the faces and coordinates still in question; a lane without a
+    // usable entry time (origin on or inside the cube, NaN) keeps the whole wave on box_color's full evaluation
+    if (DEFER) {
+        if (__builtin_amdgcn_ballot_w64(unclear) != 0ull) return false;
+    } else {
+        const bool hard = unclear && !(tn > 1e-3f && tn < 1e30f);
+        if (__builtin_amdgcn_ballot_w64(unclear) != 0ull && __builtin_amdgcn_ballot_w64(hard) == 0ull) {
+            box_resolve<N>(org, dir, sqrtf(sq), margin, near, tn, vK, unclear, hit, x);
+            unclear = false;
+        }
+    }
 #else
     unclear = maybe;
 #endif
@@ -511,7 +583,7 @@ __device__ __forceinline__ void box_pixel(const NtTarget &tg, const PixelRef &pr
                 qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;    // the value may round to just above 1: clamped
                 qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
                 emit_plain(tg, pr, (hit || x > 0.0f) ? qr : 0u, qgb);
-                return;
+                return true;
             }
         }
         const float in = x / sqrtf(sq);
@@ -524,17 +596,20 @@ __device__ __forceinline__ void box_pixel(const NtTarget &tg, const PixelRef &pr
         } else {
             box_background(in, r, g, b);
         }
-    } else {
+    } else if (!DEFER) {
         const float len = sqrtf(sq);
 #pragma unroll
         for (int j = 0; j < N; ++j) dir[j] = dir[j] / len;
         box_color<N>(org, dir, maybe, r, g, b);
+    } else {
+        return false;
     }
     if (PLAIN || plain_rgb(tg)) {
         emit_plain(tg, pr, plain_quantize(tg, r), plain_quantize(tg, g));       // g == b
-        return;
+        return true;
     }
     emit_pixel(tg, pr, r, g, b);
+    return true;
 }
 
 // A lane renders BoxRows<N> = 4 pixels of one image column (a block: 64 columns x 16 rows; a wave still writes 64
@@ -577,67 +652,122 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         return;
     }
     // the wave's number as a scalar: everything that depends on the row alone stays on the scalar unit
-    const int row0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * BoxRows<N>::value;
-    // sy and up[0]*sy of the wave's rows, one row per lane: the loop reads them back with v_readlane (computed while
-    // every lane is still active -- lanes past the right edge leave next)
-    float v_sy, v_us0;
-    {
-        const int lorow = tg.row_begin + row0 + (tid & 63);
+    constexpr int R = BoxRows<N>::value;
+    const int row0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * R;
+    if (PLAIN) {
+        // ---- packed RGB, at most 10 bits a channel: the lean loop ----
+        // Row bookkeeping is done once, one row per lane (lane l <-> row row0 + l), and read back with v_readlane:
+        // sy, up[0]*sy, the row's byte offset, whether the row exists.  Every lane stays active for that -- lanes past
+        // the right edge redo the last pixel (the same dword, the same value) instead of leaving.
+        const int lane = tid & 63;
+        const int lorow = tg.row_begin + row0 + lane;
         int ly = lorow;
         if (tg.band_world > 1) {
             const int band = lorow / tg.band_rows;
             ly = (band * tg.band_world + tg.band_rank) * tg.band_rows + (lorow - band * tg.band_rows);
         }
-        v_sy = tg.fovI * ((float)ly - tg.half_h);
-        v_us0 = up[0] * v_sy;
-    }
-    int x = (int)blockIdx.x * 64 + (tid & 63);
-    if (PLAIN) {
-        // lanes past the right edge redo the last pixel (the same dword, the same value) rather than leave: the
-        // v_readlane above needs lanes 0..7 alive whatever the width
+        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < R && row0 + lane < tg.row_count && ly < tg.height);
+        const float v_sy = tg.fovI * ((float)ly - tg.half_h);
+        const float v_us0 = up[0] * v_sy;
+        const long long v_off = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? lorow : ly) * tg.pitch;
+        const int v_off_lo = (int)v_off, v_off_hi = (int)(v_off >> 32);
+        int x = (int)blockIdx.x * 64 + lane;
         x = x < tg.width ? x : tg.width - 1;
-    } else if (x >= tg.width) {
-        return;
-    }
-    const float sx = tg.fovI * ((float)x - tg.half_w);
-    float base[N];
+        const long long xoff = (long long)x * tg.bpp;
+        const float sx = tg.fovI * ((float)x - tg.half_w);
+        float base[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
-    // the culling bits of the wave's rows, fetched together ahead of the loop (bit rr: row0 + rr may reach the cube)
-    uint32_t rowmask = ~0u;
-    if (tg.cull) {
-        rowmask = 0u;
+        for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
+        // the culling bits of the wave's rows (bit rr: row0 + rr may reach the cube)
+        uint32_t rowmask = 0u;
 #pragma unroll
-        for (int rr = 0; rr < BoxRows<N>::value; ++rr) {
+        for (int rr = 0; rr < R; ++rr) {
             const int row = row0 + rr < tg.row_count ? row0 + rr : tg.row_count - 1;
             const uint32_t bits = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 5)];
             rowmask |= ((bits >> (blockIdx.x & 31)) & 1u) << rr;
         }
-    }
-    // Background rows of quantised formats need |dir|^2 only to ~2^-19 (see the guard below): as a quadratic in sy,
-    //   |base - up*sy|^2 = base.base - 2*sy*(base.up) + sy^2*(up.up),
-    // it costs two fma per row instead of the N-1 other components and their squares.  Its absolute error is
-    // ~2.7n*2^-24*(base.base + sy^2 up.up), and that is relative to the result as long as the cross term cannot
-    // cancel the squares: lanes check (base.up)^2 <= base.base*up.up/16 (any sane camera: up is orthogonal to
-    // forward and right), and a wave with a lane that fails it never takes the shortcut.
-    const bool quant = PLAIN;                     // the launcher picks PLAIN for exactly the formats this applies to
-    float bb = 0.0f, m2bu = 0.0f, uu = 0.0f;
-    bool fastsq = false;
-    if (quant) {
-        float bu = 0.0f;
+        // Background rows need |dir|^2 only to ~2^-19 (see the guard below): as a quadratic in sy,
+        //   |base - up*sy|^2 = base.base - 2*sy*(base.up) + sy^2*(up.up),
+        // it costs two fma per row instead of the N-1 other components and their squares.  Its absolute error is
+        // ~2.7n*2^-24*(base.base + sy^2 up.up), and that is relative to the result as long as the cross term cannot
+        // cancel the squares: lanes check (base.up)^2 <= base.base*up.up/16 (any sane camera: up is orthogonal to
+        // forward and right), and a wave with a lane that fails it never takes the shortcut.
+        float bb = 0.0f, bu = 0.0f, uu = 0.0f;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             bb = fmaf(base[j], base[j], bb);
             bu = fmaf(base[j], up[j], bu);
             uu = fmaf(up[j], up[j], uu);
         }
-        m2bu = -2.0f * bu;
-        fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
+        const float m2bu = -2.0f * bu;
+        const bool fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
+        const float maxv = (float)tg.plain_maxval;
+        uint32_t todo = valid, quick = 0u;      // rows for the full treatment / rows painted as background outright
+        if (fastsq) {
+            quick = valid & ~rowmask;
+            todo = valid & rowmask;
+        }
+        while (quick != 0u) {
+            const int rr = __builtin_ctz(quick);
+            quick &= quick - 1u;
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+            const float us0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_us0), rr));
+            const float d0 = base[0] - us0;                           // dir[0], bit for bit
+            const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
+            // round(|dir[0]|/len * maxval), as in box_pixel, with the guard widened for sqa: sqa is within
+            // (3.7n+4)*2^-24 of the reference's sum, so t is within ~22*2^-24 < 2^-19.4 of its value (n <= 8); guard 2^-18
+            const float t = (fabsf(d0) * __builtin_amdgcn_rsqf(sqa)) * maxv;
+            const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);
+            if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
+                todo |= 1u << rr;                                     // a lane too close to a rounding boundary
+                continue;
+            }
+            uint32_t q = (uint32_t)(t + 0.5f);
+            q = q < tg.plain_maxval ? q : tg.plain_maxval;
+            PixelRef pr;
+            pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+            emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
+        }
+        while (todo != 0u) {
+            const int rr = __builtin_ctz(todo);
+            todo &= todo - 1u;
+            const bool rowhit = (rowmask >> rr) & 1u;
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+            PixelRef pr;
+            pr.x = x;
+            pr.y = 0;
+            pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+            pr.hit_index = 0;
+            pr.valid = true;
+#pragma unroll
+            for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+            float sq = dir[0] * dir[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+            if (!box_pixel<N, true, true>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit)) {
+                // a lane needs the reference's face-by-face arithmetic: leave the stretch to box_redo_kernel
+                if (lane == 0)
+                    atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.cull_words + (blockIdx.x >> 5),
+                             1u << (blockIdx.x & 31));
+            }
+        }
+        return;
     }
-    for (int rr = 0; rr < BoxRows<N>::value; ++rr) {
+    // ---- any other format ----
+    const int x = (int)blockIdx.x * 64 + (tid & 63);
+    if (x >= tg.width) return;
+    const float sx = tg.fovI * ((float)x - tg.half_w);
+    float base[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
+    for (int rr = 0; rr < R; ++rr) {
         const int row = row0 + rr;                      // relative to row_begin; the same for the whole wave
         if (row >= tg.row_count) return;
-        const bool rowhit = (rowmask >> rr) & 1u;
+        bool rowhit = true;
+        if (tg.cull) {
+            const uint32_t bits = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 5)];
+            rowhit = (bits >> (blockIdx.x & 31)) & 1u;
+        }
         const int orow = tg.row_begin + row;
         int y = orow;
         if (tg.band_world > 1) {
@@ -651,31 +781,64 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         pr.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
         pr.hit_index = 0;
         pr.valid = true;
-        if (quant && fastsq) {
-            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
-            const float us0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_us0), rr));
-            const float d0 = base[0] - us0;                           // dir[0], bit for bit
-            const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
-            if (!rowhit || __builtin_amdgcn_ballot_w64(box_may_hit(N, dots, sx, sy, sqa)) == 0ull) {
-                // background: round(|dir[0]|/len * maxval), as in box_pixel, with the guard widened for sqa:
-                // sqa is within (3.7n+4)*2^-24 of the reference's sum, so t is within ~22*2^-24 < 2^-19.4 of its value (n <= 8); guard 2^-18
-                const float t = (fabsf(d0) * __builtin_amdgcn_rsqf(sqa)) * (float)tg.plain_maxval;
-                const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);
-                if (__builtin_amdgcn_ballot_w64(!clear) == 0ull) {
-                    uint32_t q = (uint32_t)(t + 0.5f);
-                    q = q < tg.plain_maxval ? q : tg.plain_maxval;
-                    emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
-                    continue;
-                }
-            }
-        }
         const float sy = tg.fovI * ((float)y - tg.half_h);
 #pragma unroll
         for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
         float sq = dir[0] * dir[0];
 #pragma unroll
         for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-        box_pixel<N, PLAIN>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit);
+        box_pixel<N, false>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit);
+    }
+}
+
+// The stretches box_kernel<N, true> left behind (tg.redo): one wave per (frame, row, word of 32 stretches), every set
+// bit rendered with the complete box_pixel -- classification, box_resolve, box_color.
+template <int N>
+__global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarget tg) {
+    const int tid = (int)threadIdx.x;
+    const int row = (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (row >= tg.row_count) return;
+    uint32_t todo = tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + blockIdx.x];
+    if (todo == 0u) return;
+    float org[N], right[N], up[N], fwd[N], dir[N];
+    load_camera<N>(cam, org, right, up, fwd);
+    float margin = fabsf(org[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
+    margin = 1e-4f * (1.0f + margin);
+    float dots[4];
+    if (cam.buf) {
+        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
+    } else {
+        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
+    }
+    const int orow = tg.row_begin + row;
+    int y = orow;
+    if (tg.band_world > 1) {
+        const int band = orow / tg.band_rows;
+        y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+    }
+    if (y >= tg.height) return;
+    const float sy = tg.fovI * ((float)y - tg.half_h);
+    while (todo != 0u) {
+        const int bit = __builtin_ctz(todo);
+        todo &= todo - 1u;
+        int x = ((int)blockIdx.x * 32 + bit) * 64 + (tid & 63);
+        x = x < tg.width ? x : tg.width - 1;            // as in box_kernel<N, true>
+        PixelRef pr;
+        pr.x = x;
+        pr.y = y;
+        pr.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+        pr.hit_index = 0;
+        pr.valid = true;
+        const float sx = tg.fovI * ((float)x - tg.half_w);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dir[j] = (fwd[j] + right[j] * sx) - up[j] * sy;
+        float sq = dir[0] * dir[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+        box_pixel<N, true, false>(tg, pr, org, dir, sq, dots, sx, sy, margin);
     }
 }
 
@@ -732,6 +895,7 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
     if (row < tg.row_count && (threadIdx.x & 31) == 0) {
         const size_t at = ((size_t)blockIdx.z * tg.row_count + row) * words + word;
         out[at] = (threadIdx.x & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
+        tg.redo[at] = 0u;
     }
 }
 
@@ -3040,20 +3204,28 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     dim3 grid;
     grid_for(tg, 64, tg.colors_out ? 4 : 4 * BoxRows<N>::value, li.nframes, grid);
     tg.cull = nullptr;
+    tg.redo = nullptr;
     tg.cull_words = 0;
     if (li.cull_buf && !tg.colors_out && BoxRows<N>::value > 1) {
         const int ncols = (tg.width + 63) / 64, words = (ncols + 31) / 32;
         const long long threads = (long long)tg.row_count * words * 32;
+        tg.redo = li.cull_buf + (size_t)li.nframes * tg.row_count * words;
+        tg.cull_words = words;
         hipLaunchKernelGGL(box_cull_kernel<N>, dim3((unsigned)((threads + 255) / 256), 1, (unsigned)li.nframes), dim3(256), 0,
                            (hipStream_t)li.stream, cf, tg, li.cull_buf, words, ncols);
         tg.cull = li.cull_buf;
-        tg.cull_words = words;
     }
-    // the common packed-RGB formats get the kernel with the format tests compiled out
-    if (tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4 && !tg.colors_out)
+    // the common packed-RGB formats get the kernel with the format tests compiled out; it leaves the stretches that
+    // need the reference's face-by-face arithmetic to a second, small launch (it needs the bitmaps for that)
+    if ((tg.redo || BoxRows<N>::value == 1) && tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4 &&
+        !tg.colors_out) {
         hipLaunchKernelGGL((box_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
-    else
+        if (BoxRows<N>::value > 1)
+            hipLaunchKernelGGL(box_redo_kernel<N>, dim3((unsigned)tg.cull_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes),
+                               dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+    } else {
         hipLaunchKernelGGL((box_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+    }
     return 0;
 }
 
