@@ -205,11 +205,13 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": float(own_rows) * W * fmt.bytes_per_pixel * F,
-                     "kernel": "box_kernel<6>", "avg_launch_us": round(kernel_us, 2),
+                     "kernel": "box_kernel<6, true> (with box_cull_kernel<6> before it and box_redo_kernel<6> after it: "
+                               "one nt_render_frames_device call = these three)",
+                     "avg_launch_us": round(kernel_us, 2),
                      "algorithmic_bytes_per_ray": fmt.bytes_per_pixel,
                      "note": "BoxScene reads no scene memory: the only algorithmic HBM traffic is the packed framebuffer "
-                             "(4 B/ray); the kernel is fp32-VALU/issue bound (see DESIGN.md), so the HBM fraction is "
-                             "structurally small"},
+                             "(4 B/ray); the kernels are VALU- and scalar-issue bound (see DESIGN.md), so the HBM "
+                             "fraction is structurally small; avg_launch_us spans the three kernels of a call"},
         "delivery": {"what": "RCCL gather to rank 0" if world > 1 else "D2H copy to pinned host memory",
                      "ms_per_frame": round(gather_ms, 4), "verified_equal_to_single_gpu_frame": gather_ok,
                      "value_incl_delivery": round(float(W) * H * F / ((ms_per_step + gather_ms * F) * 1e-3) / 1e6, 1)},
