@@ -598,7 +598,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         if (!tg.colors_out && !(ec && atoi(ec) == 0)) {
             // one bit per 64-pixel stretch of a row: can any of its rays reach the cube? (box_cull_kernel)
             const size_t words = (size_t)(((tg.width + 63) / 64 + 31) / 32);
-            if (int e = ds->cull.ensure((size_t)2 * job.nframes * tg.row_count * words * sizeof(uint32_t))) return e;
+            if (int e = ds->cull.ensure((size_t)5 * job.nframes * tg.row_count * words * sizeof(uint32_t))) return e;
             li.cull_buf = (uint32_t *)ds->cull.p;
         }
         r = nt_launch_box(li, cam, tg);

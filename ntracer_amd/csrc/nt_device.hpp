@@ -51,13 +51,15 @@ struct NtTarget {
     // two-pass renders of lit scenes: primary hits found by the packet kernel, [frame][row][x] records of 16 bytes
     // (dist, item, lane, -); nullptr otherwise
     const void *hits;
-    // BoxScene: one bit per (frame, owned row, 64-pixel column) -- 0: no ray of that stretch can reach the cube
-    // (box_cull_kernel); [frame][row][cull_words] dwords, or nullptr
+    // BoxScene: four bits per (frame, owned row, 64-pixel stretch), eight stretches to a dword, from box_cull_kernel:
+    //   0: no ray of the stretch can reach the cube; 1..8: every ray of it clearly hits face K = code - 1;
+    //   15: look at each ray.  [frame][row][cull_words] dwords, or nullptr
     const uint32_t *cull;
     int cull_words;
-    // same shape: box_kernel sets the bit of a stretch it leaves to box_redo_kernel (a lane needed the reference's
-    // own face-by-face arithmetic); cleared by box_cull_kernel
+    // one bit per stretch, [frame][row][redo_words] dwords: box_kernel sets the bit of a stretch it leaves to
+    // box_redo_kernel (a lane needed the reference's own face-by-face arithmetic); cleared by box_cull_kernel
     uint32_t *redo;
+    int redo_words;
 };
 
 // Camera rows used by the ray source (camera.hpp:40-45): origin, right, up, forward.
@@ -133,7 +135,7 @@ struct NtLaunchInfo {
     int hit_frames;
     float *numer_buf;         // scratch for the packet kernel's plane numerators: numer_frames * n_batches * 4 floats
     int numer_frames;
-    uint32_t *cull_buf;       // BoxScene: scratch for the row culling bits, 2 * nframes * row_count * ceil(ceil(width/64)/32) dwords: culling bits, then redo bits (or nullptr)
+    uint32_t *cull_buf;       // BoxScene: scratch for the row culling bits, 5 * nframes * row_count * ceil(ceil(width/64)/32) dwords: stretch codes, then redo bits (or nullptr)
 };
 
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);

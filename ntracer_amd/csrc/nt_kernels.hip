@@ -430,10 +430,16 @@ __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir
     }
 }
 
+// m of box_classify / box_resolve / box_cull_kernel, per unit of 1 + max|o_j|.  What it has to dominate:
+// ROUNDING_FUZZ (1.2e-6), the reference's own rounding in p_j (<= (5|o_j| + 6)*2^-24) and the v_rcp_f32 arithmetic
+// here (~2^-22*(1 + |o_j|)): under 2e-6*(1 + max|o_j|) together, 15x below this.
+#ifndef NT_BOX_MARGIN
+#define NT_BOX_MARGIN 3e-5f
+#endif
 // Which rays need the exact evaluation at all?  Everything below works on the UNNORMALISED direction v
 // (p_j(tau) = o_j + v_j*tau; the reference's dist is tau*|v|), with reciprocals from v_rcp_f32, and sorts a lane
-// that may hit into one of three classes.  m = 1e-4*(1 + max|o_j|) is ~100x the sum of ROUNDING_FUZZ and every
-// rounding error involved (the reference's p_j carry ~(n+6)*2^-24*(1+|o_j|), the ones here ~2^-22*(1+|o_j|)).
+// that may hit into one of three classes.  m = NT_BOX_MARGIN*(1 + max|o_j|) dominates the sum of ROUNDING_FUZZ and
+// every rounding error involved (see NT_BOX_MARGIN).
 //   miss      the ray (tau > 0) stays outside the cube grown to 1+m.  Every point the reference accepts has
 //             |p_i| = 1, |p_j| <= 1+FUZZ at a dist > 0, so the reference finds no face either.
 //   hit at K  K = the entry face reached last, at tau_K; tau_K is clearly positive; at tau_K every other
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
     float margin = fabsf(org[0]);
 #pragma unroll
     for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
-    margin = 1e-4f * (1.0f + margin);
+    margin = NT_BOX_MARGIN * (1.0f + margin);
     float dots[4];
     if (cam.buf) {
         const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
@@ -678,13 +684,14 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         float base[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
-        // the culling bits of the wave's rows (bit rr: row0 + rr may reach the cube)
-        uint32_t rowmask = 0u;
+        // what box_cull_kernel found out about the wave's rows, four bits a row (row rr in bits 4rr..4rr+3)
+        static_assert(R <= 8, "eight row codes to a dword");
+        uint32_t rowcodes = 0u;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const int row = row0 + rr < tg.row_count ? row0 + rr : tg.row_count - 1;
-            const uint32_t bits = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 5)];
-            rowmask |= ((bits >> (blockIdx.x & 31)) & 1u) << rr;
+            const uint32_t codes = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 3)];
+            rowcodes |= ((codes >> (4 * (blockIdx.x & 7))) & 15u) << (4 * rr);
         }
         // Background rows need |dir|^2 only to ~2^-19 (see the guard below): as a quadratic in sy,
         //   |base - up*sy|^2 = base.base - 2*sy*(base.up) + sy^2*(up.up),
@@ -702,10 +709,26 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         const float m2bu = -2.0f * bu;
         const bool fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
         const float maxv = (float)tg.plain_maxval;
-        uint32_t todo = valid, quick = 0u;      // rows for the full treatment / rows painted as background outright
+        // rows painted as background outright / rows that are one face throughout / rows for the full treatment
+        uint32_t quick = 0u, inner = 0u, todo = valid;
+        // up[K]*sy of the lane's row, K = its face if it is of the second kind
+        float v_usK = 0.0f;
         if (fastsq) {
-            quick = valid & ~rowmask;
-            todo = valid & rowmask;
+            uint32_t zero = 0u, full = 0u;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const uint32_t c = (rowcodes >> (4 * rr)) & 15u;
+                zero |= (c == 0u ? 1u : 0u) << rr;
+                full |= (c == 15u ? 1u : 0u) << rr;
+            }
+            quick = valid & zero;
+            todo = valid & full;
+            inner = valid & ~zero & ~full;
+            const uint32_t lk = ((rowcodes >> (4 * (lane & 7))) & 15u) - 1u;
+            float upK = up[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) upK = lk == (uint32_t)j ? up[j] : upK;
+            v_usK = upK * v_sy;
         }
         while (quick != 0u) {
             const int rr = __builtin_ctz(quick);
@@ -728,10 +751,36 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
             pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
             emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
         }
+        while (inner != 0u) {
+            // every ray of the row's stretch hits face K (box_cull_kernel): the colour is |dir[K]|/len * (1, .5, .5)
+            const int rr = __builtin_ctz(inner);
+            inner &= inner - 1u;
+            const uint32_t K = ((rowcodes >> (4 * rr)) & 15u) - 1u;
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+            const float usK = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_usK), rr));
+            float bK = base[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) bK = K == (uint32_t)j ? base[j] : bK;
+            const float dK = bK - usK;                                // dir[K], bit for bit
+            const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
+            const float t = (fabsf(dK) * __builtin_amdgcn_rsqf(sqa)) * maxv, th = t * 0.5f;
+            const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f) &&
+                               fabsf(__builtin_amdgcn_fractf(th) - 0.5f) > fmaf(th, 0x1p-18f, 0x1p-18f);
+            if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
+                todo |= 1u << rr;
+                continue;
+            }
+            uint32_t qr = (uint32_t)(t + 0.5f), qgb = (uint32_t)(th + 0.5f);
+            qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
+            qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;
+            PixelRef pr;
+            pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+            emit_plain(tg, pr, qr, qgb);
+        }
         while (todo != 0u) {
             const int rr = __builtin_ctz(todo);
             todo &= todo - 1u;
-            const bool rowhit = (rowmask >> rr) & 1u;
+            const bool rowhit = ((rowcodes >> (4 * rr)) & 15u) != 0u;
             const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
             PixelRef pr;
             pr.x = x;
@@ -747,7 +796,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
             if (!box_pixel<N, true, true>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit)) {
                 // a lane needs the reference's face-by-face arithmetic: leave the stretch to box_redo_kernel
                 if (lane == 0)
-                    atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.cull_words + (blockIdx.x >> 5),
+                    atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5),
                              1u << (blockIdx.x & 31));
             }
         }
@@ -765,8 +814,8 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         if (row >= tg.row_count) return;
         bool rowhit = true;
         if (tg.cull) {
-            const uint32_t bits = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 5)];
-            rowhit = (bits >> (blockIdx.x & 31)) & 1u;
+            const uint32_t codes = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 3)];
+            rowhit = ((codes >> (4 * (blockIdx.x & 7))) & 15u) != 0u;
         }
         const int orow = tg.row_begin + row;
         int y = orow;
@@ -798,14 +847,14 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
     const int tid = (int)threadIdx.x;
     const int row = (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);
     if (row >= tg.row_count) return;
-    uint32_t todo = tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + blockIdx.x];
+    uint32_t todo = tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + blockIdx.x];
     if (todo == 0u) return;
     float org[N], right[N], up[N], fwd[N], dir[N];
     load_camera<N>(cam, org, right, up, fwd);
     float margin = fabsf(org[0]);
 #pragma unroll
     for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
-    margin = 1e-4f * (1.0f + margin);
+    margin = NT_BOX_MARGIN * (1.0f + margin);
     float dots[4];
     if (cam.buf) {
         const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
@@ -842,23 +891,31 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
     }
 }
 
-// Which 64-pixel stretches of which rows can reach the cube at all?  One thread per stretch: the rays of a stretch
-// are v = vc + right*e with vc the direction through its middle and |e| <= 32*fovI, so a ray that comes within
-// h = 1 + 2m + 1e-3 of the cube in every coordinate at some tau > 0 (every ray the reference could call a hit
-// does, see box_classify) satisfies, with g_j = 32*fovI*|right_j| (+1e-6 for the rounding of v itself),
-//     (vc_j + g_j)*tau >= -h - o_j     and     (vc_j - g_j)*tau <= h - o_j         for every j:
-// 2n half-lines in tau.  An empty intersection clears the stretch's bit, and box_kernel then paints background
-// there without looking further.  Convexity makes this sharp: the bits left set are the stretches within half a
-// stretch of the cube's silhouette.  Reciprocals are approximate (v_rcp_f32); the 1e-3 in h is ~1000x their error.
+// What can be said about a whole 64-pixel stretch of a row?  One thread per stretch.  Its rays are v = vc + right*e
+// with vc the direction through its middle and |e| <= 32*fovI: v_j lies in [vc_j - g_j, vc_j + g_j],
+// g_j = 32*fovI*|right_j| (+1e-6 for the rounding of v itself).
+//  * code 0 -- no ray can reach the cube.  A ray that comes within h = 1 + 2m + 1e-3 of the cube in every coordinate
+//    at some tau > 0 (every ray the reference could call a hit does, see box_classify) satisfies
+//        (vc_j + g_j)*tau >= -h - o_j     and     (vc_j - g_j)*tau <= h - o_j         for every j:
+//    2n half-lines in tau; an empty intersection clears the stretch, and box_kernel paints background there without
+//    looking further.  Convexity makes this sharp: what is left is within half a stretch of the cube's silhouette.
+//  * code K+1 -- every ray clearly hits face K, K = the face the middle ray enters last.  With v_K of one sign over
+//    the stretch, tau_K = (s_K - o_K)/v_K ranges over [tlo, thi]; if for every other j the extremes of
+//    o_j + v_j*tau over that box stay inside 1 - m*(1 + |v_j|max/|v_K|min) (less 1e-4 for the arithmetic here), then for
+//    each ray the reference's test of face K passes with room to spare, and every other slab was entered at least
+//    m/|v_K| earlier, i.e. while p_K was outside 1+m, so no face before K can pass its j = K check (the argument of
+//    box_classify).  box_kernel shades such rows from v_K alone.
+//  * code 15 -- anything else: box_kernel classifies the rays one by one.
+// Reciprocals are approximate (v_rcp_f32); the slacks above are ~1000x their error.
 template <int N>
-__global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarget tg, uint32_t *out, int words, int ncols) {
+__global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarget tg, uint32_t *out, int ncols) {
     float org[N], right[N], up[N], fwd[N];
     load_camera<N>(cam, org, right, up, fwd);
     const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    const int rw = i >> 5;                               // (row, word): the same for a half-wave
-    const int word = rw % words, row = rw / words;
+    const int rw = i >> 5;                               // (row, 32 stretches): the same for a half-wave
+    const int word = rw % tg.redo_words, row = rw / tg.redo_words;
     const int col = word * 32 + (i & 31);
-    bool keep = false;
+    uint32_t code = 0u;
     if (row < tg.row_count && col < ncols) {
         const int orow = tg.row_begin + row;
         int y = orow;
@@ -869,18 +926,22 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
         float omax = fabsf(org[0]);
 #pragma unroll
         for (int j = 1; j < N; ++j) omax = fmaxf(omax, fabsf(org[j]));
-        const float h = 1.0f + 2e-4f * (1.0f + omax) + 1e-3f;
+        const float m = NT_BOX_MARGIN * (1.0f + omax);
+        const float h = 1.0f + 2.0f * m + 1e-3f;
         const float sxc = tg.fovI * (((float)(col * 64) + 31.5f) - tg.half_w);
         const float sy = tg.fovI * ((float)y - tg.half_h);
         const float spread = 32.0f * tg.fovI;
         float tlo = 0.0f, thi = INFINITY;
         bool dead = false;
+        float vc[N], g[N];
+        float tn = -INFINITY, vK = 0.0f, gK = 0.0f, oK = 0.0f;
+        int K = 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const float vc = (fwd[j] + right[j] * sxc) - up[j] * sy;
-            const float g = fmaf(spread, fabsf(right[j]), 1e-6f);
-            const float pa = vc + g, qa = -h - org[j];
-            const float pb = vc - g, qb = h - org[j];
+            vc[j] = (fwd[j] + right[j] * sxc) - up[j] * sy;
+            g[j] = fmaf(spread, fabsf(right[j]), 1e-6f);
+            const float pa = vc[j] + g[j], qa = -h - org[j];
+            const float pb = vc[j] - g[j], qb = h - org[j];
             const float ra = qa * __builtin_amdgcn_rcpf(pa), rb = qb * __builtin_amdgcn_rcpf(pb);
             if (pa > 0.0f) tlo = fmaxf(tlo, ra);
             else if (pa < 0.0f) thi = fminf(thi, ra);
@@ -888,14 +949,39 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
             if (pb > 0.0f) thi = fminf(thi, rb);
             else if (pb < 0.0f) tlo = fmaxf(tlo, rb);
             else if (pb == 0.0f && qb < 0.0f) dead = true;
+            // the middle ray's entry into slab j (any K is verified below, so accuracy only matters for the yield)
+            const float nr = ((vc[j] < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc[j]);
+            if (nr > tn) { tn = nr; vK = vc[j]; gK = g[j]; oK = org[j]; K = j; }
         }
-        keep = !(dead || tlo > thi);                    // a NaN keeps the stretch
+        if (!(dead || tlo > thi)) {                      // a NaN keeps the stretch
+            code = 15u;
+            const float vKa = vK - gK, vKb = vK + gK;
+            if (N <= 8 && vKa * vKb > 0.0f) {
+                const float num = (vK < 0.0f ? 1.0f : -1.0f) - oK;
+                const float t1 = num * __builtin_amdgcn_rcpf(vKa), t2 = num * __builtin_amdgcn_rcpf(vKb);
+                const float t_lo = fminf(t1, t2) * (1.0f - 1e-6f), t_hi = fmaxf(t1, t2) * (1.0f + 1e-6f);
+                const float rK = m * __builtin_amdgcn_rcpf(fminf(fabsf(vKa), fabsf(vKb))) * (1.0f + 1e-6f);
+                bool ok = t_lo > 1e-3f && t_hi < 1e30f;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float va = vc[j] - g[j], vb = vc[j] + g[j];
+                    const float pmax = org[j] + fmaxf(vb * t_lo, vb * t_hi);
+                    const float pmin = org[j] + fminf(va * t_lo, va * t_hi);
+                    const float lim = (1.0f - m - 1e-4f) - fmaxf(fabsf(va), fabsf(vb)) * rK;
+                    ok = ok && (j == K || (pmax <= lim && pmin >= -lim));
+                }
+                if (ok) code = (uint32_t)K + 1u;
+            }
+        }
     }
-    const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
-    if (row < tg.row_count && (threadIdx.x & 31) == 0) {
-        const size_t at = ((size_t)blockIdx.z * tg.row_count + row) * words + word;
-        out[at] = (threadIdx.x & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
-        tg.redo[at] = 0u;
+    // eight stretches to a dword
+    uint32_t packed = code << (4 * (threadIdx.x & 7));
+    packed |= (uint32_t)__shfl_xor((int)packed, 1, 64);
+    packed |= (uint32_t)__shfl_xor((int)packed, 2, 64);
+    packed |= (uint32_t)__shfl_xor((int)packed, 4, 64);
+    if (row < tg.row_count) {
+        if ((threadIdx.x & 7) == 0) out[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (col >> 3)] = packed;
+        if ((threadIdx.x & 31) == 0) tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + word] = 0u;
     }
 }
 
@@ -3206,13 +3292,15 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     tg.cull = nullptr;
     tg.redo = nullptr;
     tg.cull_words = 0;
+    tg.redo_words = 0;
     if (li.cull_buf && !tg.colors_out && BoxRows<N>::value > 1) {
-        const int ncols = (tg.width + 63) / 64, words = (ncols + 31) / 32;
-        const long long threads = (long long)tg.row_count * words * 32;
-        tg.redo = li.cull_buf + (size_t)li.nframes * tg.row_count * words;
-        tg.cull_words = words;
+        const int ncols = (tg.width + 63) / 64;
+        tg.redo_words = (ncols + 31) / 32;
+        tg.cull_words = 4 * tg.redo_words;
+        const long long threads = (long long)tg.row_count * tg.redo_words * 32;
+        tg.redo = li.cull_buf + (size_t)li.nframes * tg.row_count * tg.cull_words;
         hipLaunchKernelGGL(box_cull_kernel<N>, dim3((unsigned)((threads + 255) / 256), 1, (unsigned)li.nframes), dim3(256), 0,
-                           (hipStream_t)li.stream, cf, tg, li.cull_buf, words, ncols);
+                           (hipStream_t)li.stream, cf, tg, li.cull_buf, ncols);
         tg.cull = li.cull_buf;
     }
     // the common packed-RGB formats get the kernel with the format tests compiled out; it leaves the stretches that
@@ -3221,7 +3309,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         !tg.colors_out) {
         hipLaunchKernelGGL((box_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
         if (BoxRows<N>::value > 1)
-            hipLaunchKernelGGL(box_redo_kernel<N>, dim3((unsigned)tg.cull_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes),
+            hipLaunchKernelGGL(box_redo_kernel<N>, dim3((unsigned)tg.redo_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes),
                                dim3(256), 0, (hipStream_t)li.stream, cf, tg);
     } else {
         hipLaunchKernelGGL((box_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
