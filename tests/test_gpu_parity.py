@@ -138,6 +138,25 @@ def test_box_stress_cameras_bytes_and_floats_equal_oracle(n):
             assert np.array_equal(got.view(np.uint32), osc.colors_at(xs, ys, w, h).view(np.uint32)), (n, k)
 
 
+def test_box_wide_rows_and_the_kernel_without_stretch_codes(monkeypatch):
+    """More than 2048 pixels a row (two words of redo bits, several of stretch codes), a width that is not a multiple
+    of 64, and the same frames through the general kernel (NTRACER_BOX_CULL=0: no pre-kernel, no second pass)."""
+    rng = np.random.default_rng(77)
+    for n, w, h in ((4, 4100, 11), (6, 2307, 19), (8, 130, 70)):
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        axes = np.ascontiguousarray(q, np.float32)
+        origin = (-axes[2] * np.float32(2.2) + np.float32(0.3) * axes[0]).astype(np.float32)
+        sc = tracern.BoxScene(n)
+        sc._set_camera_arrays(origin, axes)
+        ref = ob.OracleScene(n, origin, axes).render(w, h, fx.RGBX8, threads=7)
+        img = render_host(sc, fmt_of(w, h, fx.RGBX8))
+        assert np.array_equal(img, ref), (n, w, h, int((img != ref).sum()))
+        monkeypatch.setenv("NTRACER_BOX_CULL", "0")
+        img0 = render_host(sc, fmt_of(w, h, fx.RGBX8))
+        monkeypatch.delenv("NTRACER_BOX_CULL")
+        assert np.array_equal(img0, ref), (n, w, h)
+
+
 def test_box10_4096_both_kernels_properties_and_samples(monkeypatch):
     """config 5 at full size, 4096x4096, through the compile-time-N kernel (default for n <= 10) and through the
     run-time-n kernel (NTRACER_FORCE_VAR; the only one for n > 10): identical frames.  Oracle on sampled rows; at
