@@ -626,7 +626,7 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
 #define NT_BOXROWS 8
 #endif
 template <int N> struct BoxRows { static constexpr int value = N <= 8 ? NT_BOXROWS : 1; };
-template <int N, bool PLAIN>
+template <int N, bool PLAIN, int ROWS = BoxRows<N>::value>
 __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg) {
     const int tid = (int)threadIdx.x;
     float org[N], right[N], up[N], fwd[N], dir[N];
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
     } else {
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
     }
-    if ((!PLAIN && tg.colors_out) || BoxRows<N>::value == 1) {
+    if ((!PLAIN && tg.colors_out) || ROWS == 1) {
         // one pixel per lane: probe mode (listed pixels), and n > 8
         const PixelRef pr = locate_pixel<64, 4>(tg, tid & 63, tid >> 6, tid);
         if (!pr.valid) return;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         return;
     }
     // the wave's number as a scalar: everything that depends on the row alone stays on the scalar unit
-    constexpr int R = BoxRows<N>::value;
+    constexpr int R = ROWS;
     const int row0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * R;
     if (PLAIN) {
         // ---- packed RGB, at most 10 bits a channel: the lean loop ----
@@ -685,13 +685,13 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
 #pragma unroll
         for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
         // what box_cull_kernel found out about the wave's rows, four bits a row (row rr in bits 4rr..4rr+3)
-        static_assert(R <= 8, "eight row codes to a dword");
-        uint32_t rowcodes = 0u;
+        static_assert(R <= 16, "sixteen row codes to a qword");
+        unsigned long long rowcodes = 0ull;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const int row = row0 + rr < tg.row_count ? row0 + rr : tg.row_count - 1;
             const uint32_t codes = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 3)];
-            rowcodes |= ((codes >> (4 * (blockIdx.x & 7))) & 15u) << (4 * rr);
+            rowcodes |= (unsigned long long)((codes >> (4 * (blockIdx.x & 7))) & 15u) << (4 * rr);
         }
         // Background rows need |dir|^2 only to ~2^-19 (see the guard below): as a quadratic in sy,
         //   |base - up*sy|^2 = base.base - 2*sy*(base.up) + sy^2*(up.up),
@@ -717,14 +717,14 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
             uint32_t zero = 0u, full = 0u;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
-                const uint32_t c = (rowcodes >> (4 * rr)) & 15u;
+                const uint32_t c = (uint32_t)(rowcodes >> (4 * rr)) & 15u;
                 zero |= (c == 0u ? 1u : 0u) << rr;
                 full |= (c == 15u ? 1u : 0u) << rr;
             }
             quick = valid & zero;
             todo = valid & full;
             inner = valid & ~zero & ~full;
-            const uint32_t lk = ((rowcodes >> (4 * (lane & 7))) & 15u) - 1u;
+            const uint32_t lk = ((uint32_t)(rowcodes >> (4 * (lane & 15))) & 15u) - 1u;
             float upK = up[0];
 #pragma unroll
             for (int j = 1; j < N; ++j) upK = lk == (uint32_t)j ? up[j] : upK;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
             // every ray of the row's stretch hits face K (box_cull_kernel): the colour is |dir[K]|/len * (1, .5, .5)
             const int rr = __builtin_ctz(inner);
             inner &= inner - 1u;
-            const uint32_t K = ((rowcodes >> (4 * rr)) & 15u) - 1u;
+            const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
             const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
             const float usK = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_usK), rr));
             float bK = base[0];
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         while (todo != 0u) {
             const int rr = __builtin_ctz(todo);
             todo &= todo - 1u;
-            const bool rowhit = ((rowcodes >> (4 * rr)) & 15u) != 0u;
+            const bool rowhit = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) != 0u;
             const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
             PixelRef pr;
             pr.x = x;
@@ -3307,7 +3307,14 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     // need the reference's face-by-face arithmetic to a second, small launch (it needs the bitmaps for that)
     if ((tg.redo || BoxRows<N>::value == 1) && tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4 &&
         !tg.colors_out) {
-        hipLaunchKernelGGL((box_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+        // sixteen rows a lane once there are waves to spare (the per-wave set-up is a fifth of the work at eight)
+        const long long waves8 = (long long)grid.x * grid.y * grid.z * 4;
+        if (BoxRows<N>::value > 1 && BoxRows<N>::value < 16 && waves8 >= 64 * 1024) {
+            grid_for(tg, 64, 4 * 16, li.nframes, grid);
+            hipLaunchKernelGGL((box_kernel<N, true, (BoxRows<N>::value > 1 ? 16 : 1)>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+        } else {
+            hipLaunchKernelGGL((box_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+        }
         if (BoxRows<N>::value > 1)
             hipLaunchKernelGGL(box_redo_kernel<N>, dim3((unsigned)tg.redo_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes),
                                dim3(256), 0, (hipStream_t)li.stream, cf, tg);
