@@ -618,14 +618,13 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
     return true;
 }
 
-// A lane renders BoxRows<N> = 4 pixels of one image column (a block: 64 columns x 16 rows; a wave still writes 64
-// consecutive pixels of a row at a time): forward + right*sx is the same for all of them, which takes a tenth of
-// the instructions off the path most rays take.
-// (n <= 8; beyond that the extra registers cost more than the shared work saves: measured on n = 10)
+// A lane renders ROWS pixels of one image column (a block: 64 columns x 4*ROWS rows; a wave still writes 64 consecutive
+// pixels of a row at a time): forward + right*sx and the wave's set-up are shared by all of them.  ROWS = BoxRows<N>
+// (8), or 16 for the packed-RGB kernel in large launches; probe mode (listed pixels) is one pixel per lane.
 #ifndef NT_BOXROWS
 #define NT_BOXROWS 8
 #endif
-template <int N> struct BoxRows { static constexpr int value = N <= 8 ? NT_BOXROWS : 1; };
+template <int N> struct BoxRows { static constexpr int value = N <= 10 ? NT_BOXROWS : 1; };
 template <int N, bool PLAIN, int ROWS = BoxRows<N>::value>
 __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg) {
     const int tid = (int)threadIdx.x;
@@ -956,7 +955,7 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
         if (!(dead || tlo > thi)) {                      // a NaN keeps the stretch
             code = 15u;
             const float vKa = vK - gK, vKb = vK + gK;
-            if (N <= 8 && vKa * vKb > 0.0f) {
+            if (N <= 14 && vKa * vKb > 0.0f) {
                 const float num = (vK < 0.0f ? 1.0f : -1.0f) - oK;
                 const float t1 = num * __builtin_amdgcn_rcpf(vKa), t2 = num * __builtin_amdgcn_rcpf(vKb);
                 const float t_lo = fminf(t1, t2) * (1.0f - 1e-6f), t_hi = fmaxf(t1, t2) * (1.0f + 1e-6f);
