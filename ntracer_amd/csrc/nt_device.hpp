@@ -53,7 +53,7 @@ struct NtTarget {
     const void *hits;
     // BoxScene: four bits per (frame, owned row, 64-pixel stretch), eight stretches to a dword, from box_cull_kernel:
     //   0: no ray of the stretch can reach the cube; 1..8: every ray of it clearly hits face K = code - 1;
-    //   15: look at each ray.  [frame][row][cull_words] dwords, or nullptr
+    //   14: left to box_redo_kernel (redo bit already set); 15: look at each ray.  [frame][row][cull_words] dwords, or nullptr
     const uint32_t *cull;
     int cull_words;
     // one bit per stretch, [frame][row][redo_words] dwords: box_kernel sets the bit of a stretch it leaves to

@@ -713,16 +713,17 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         // up[K]*sy of the lane's row, K = its face if it is of the second kind
         float v_usK = 0.0f;
         if (fastsq) {
-            uint32_t zero = 0u, full = 0u;
+            uint32_t zero = 0u, full = 0u, skip = 0u;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
                 const uint32_t c = (uint32_t)(rowcodes >> (4 * rr)) & 15u;
                 zero |= (c == 0u ? 1u : 0u) << rr;
                 full |= (c == 15u ? 1u : 0u) << rr;
+                skip |= (c == 14u ? 1u : 0u) << rr;          // box_redo_kernel's from the start
             }
             quick = valid & zero;
             todo = valid & full;
-            inner = valid & ~zero & ~full;
+            inner = valid & ~zero & ~full & ~skip;
             const uint32_t lk = ((uint32_t)(rowcodes >> (4 * (lane & 15))) & 15u) - 1u;
             float upK = up[0];
 #pragma unroll
@@ -904,7 +905,8 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
 //    each ray the reference's test of face K passes with room to spare, and every other slab was entered at least
 //    m/|v_K| earlier, i.e. while p_K was outside 1+m, so no face before K can pass its j = K check (the argument of
 //    box_classify).  box_kernel shades such rows from v_K alone.
-//  * code 15 -- anything else: box_kernel classifies the rays one by one.
+//  * code 15 -- anything else: box_kernel classifies the rays one by one;  code 14 -- box_kernel skips the stretch and
+//    box_redo_kernel renders it (its redo bit is set here).
 // Reciprocals are approximate (v_rcp_f32); the slacks above are ~1000x their error.
 template <int N>
 __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarget tg, uint32_t *out, int ncols) {
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
         float tlo = 0.0f, thi = INFINITY;
         bool dead = false;
         float vc[N], g[N];
-        float tn = -INFINITY, vK = 0.0f, gK = 0.0f, oK = 0.0f;
+        float tn = -INFINITY, tn2 = -INFINITY, vK = 0.0f, gK = 0.0f, oK = 0.0f;
         int K = 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -950,6 +952,7 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
             else if (pb == 0.0f && qb < 0.0f) dead = true;
             // the middle ray's entry into slab j (any K is verified below, so accuracy only matters for the yield)
             const float nr = ((vc[j] < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc[j]);
+            tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);         // second-to-last entry
             if (nr > tn) { tn = nr; vK = vc[j]; gK = g[j]; oK = org[j]; K = j; }
         }
         if (!(dead || tlo > thi)) {                      // a NaN keeps the stretch
@@ -971,8 +974,13 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
                 }
                 if (ok) code = (uint32_t)K + 1u;
             }
+            // The middle ray enters two slabs within m/|v_K| of each other: box_classify would call the rays around it
+            // unclear and box_kernel would hand the stretch to box_redo_kernel after classifying all of it -- send it
+            // there directly (code 14; only a prediction: box_redo_kernel is right for any stretch).
+            if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) code = 14u;
         }
     }
+    const unsigned long long direct = __builtin_amdgcn_ballot_w64(code == 14u);      // redo bits set here
     // eight stretches to a dword
     uint32_t packed = code << (4 * (threadIdx.x & 7));
     packed |= (uint32_t)__shfl_xor((int)packed, 1, 64);
@@ -980,7 +988,8 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
     packed |= (uint32_t)__shfl_xor((int)packed, 4, 64);
     if (row < tg.row_count) {
         if ((threadIdx.x & 7) == 0) out[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (col >> 3)] = packed;
-        if ((threadIdx.x & 31) == 0) tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + word] = 0u;
+        if ((threadIdx.x & 31) == 0)
+            tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + word] = (threadIdx.x & 32) ? (uint32_t)(direct >> 32) : (uint32_t)direct;
     }
 }
 
