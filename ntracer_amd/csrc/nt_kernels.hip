@@ -708,31 +708,36 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         const float m2bu = -2.0f * bu;
         const bool fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
         const float maxv = (float)tg.plain_maxval;
-        // rows painted as background outright / rows that are one face throughout / rows for the full treatment
-        uint32_t quick = 0u, inner = 0u, todo = valid;
+        // rows painted as background outright / rows that are one face throughout / rows for the full treatment, as
+        // masks with one bit per row AT THE ROW'S NIBBLE (bit 4rr): derived from the codes with a dozen scalar
+        // operations on the whole qword
+        const unsigned long long nib = 0x1111111111111111ull;
+        unsigned long long validn = valid & 0xffffu;                       // bit rr -> bit 4rr
+        validn = (validn | (validn << 24)) & 0x000000ff000000ffull;
+        validn = (validn | (validn << 12)) & 0x000f000f000f000full;
+        validn = (validn | (validn << 6)) & 0x0303030303030303ull;
+        validn = (validn | (validn << 3)) & nib;
+        unsigned long long quick = 0ull, inner = 0ull, todo = validn;
         // up[K]*sy of the lane's row, K = its face if it is of the second kind
         float v_usK = 0.0f;
         if (fastsq) {
-            uint32_t zero = 0u, full = 0u, skip = 0u;
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) {
-                const uint32_t c = (uint32_t)(rowcodes >> (4 * rr)) & 15u;
-                zero |= (c == 0u ? 1u : 0u) << rr;
-                full |= (c == 15u ? 1u : 0u) << rr;
-                skip |= (c == 14u ? 1u : 0u) << rr;          // box_redo_kernel's from the start
-            }
-            quick = valid & zero;
-            todo = valid & full;
-            inner = valid & ~zero & ~full & ~skip;
+            const unsigned long long n = rowcodes;
+            const unsigned long long nz = (n | (n >> 1) | (n >> 2) | (n >> 3)) & nib;            // code != 0
+            const unsigned long long hi3 = ((n >> 1) & (n >> 2) & (n >> 3)) & nib;               // code is 14 or 15
+            const unsigned long long full = hi3 & n, skip = hi3 & ~n;                            // 15 / 14 (box_redo_kernel's from the start)
+            quick = validn & ~nz;
+            todo = validn & full;
+            inner = validn & nz & ~hi3;
+            (void)skip;
             const uint32_t lk = ((uint32_t)(rowcodes >> (4 * (lane & 15))) & 15u) - 1u;
             float upK = up[0];
 #pragma unroll
             for (int j = 1; j < N; ++j) upK = lk == (uint32_t)j ? up[j] : upK;
             v_usK = upK * v_sy;
         }
-        while (quick != 0u) {
-            const int rr = __builtin_ctz(quick);
-            quick &= quick - 1u;
+        while (quick != 0ull) {
+            const int rr = __builtin_ctzll(quick) >> 2;
+            quick &= quick - 1ull;
             const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
             const float us0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_us0), rr));
             const float d0 = base[0] - us0;                           // dir[0], bit for bit
@@ -742,7 +747,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
             const float t = (fabsf(d0) * __builtin_amdgcn_rsqf(sqa)) * maxv;
             const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);
             if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
-                todo |= 1u << rr;                                     // a lane too close to a rounding boundary
+                todo |= 1ull << (4 * rr);                                     // a lane too close to a rounding boundary
                 continue;
             }
             uint32_t q = (uint32_t)(t + 0.5f);
@@ -751,10 +756,10 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
             pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
             emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
         }
-        while (inner != 0u) {
+        while (inner != 0ull) {
             // every ray of the row's stretch hits face K (box_cull_kernel): the colour is |dir[K]|/len * (1, .5, .5)
-            const int rr = __builtin_ctz(inner);
-            inner &= inner - 1u;
+            const int rr = __builtin_ctzll(inner) >> 2;
+            inner &= inner - 1ull;
             const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
             const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
             const float usK = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_usK), rr));
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
             const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f) &&
                                fabsf(__builtin_amdgcn_fractf(th) - 0.5f) > fmaf(th, 0x1p-18f, 0x1p-18f);
             if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
-                todo |= 1u << rr;
+                todo |= 1ull << (4 * rr);
                 continue;
             }
             uint32_t qr = (uint32_t)(t + 0.5f), qgb = (uint32_t)(th + 0.5f);
@@ -777,9 +782,9 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
             pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
             emit_plain(tg, pr, qr, qgb);
         }
-        while (todo != 0u) {
-            const int rr = __builtin_ctz(todo);
-            todo &= todo - 1u;
+        while (todo != 0ull) {
+            const int rr = __builtin_ctzll(todo) >> 2;
+            todo &= todo - 1ull;
             const bool rowhit = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) != 0u;
             const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
             PixelRef pr;
