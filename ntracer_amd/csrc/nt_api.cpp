@@ -598,7 +598,9 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         if (!tg.colors_out && !(ec && atoi(ec) == 0)) {
             // one bit per 64-pixel stretch of a row: can any of its rays reach the cube? (box_cull_kernel)
             const size_t words = (size_t)(((tg.width + 63) / 64 + 31) / 32);
-            if (int e = ds->cull.ensure((size_t)5 * job.nframes * tg.row_count * words * sizeof(uint32_t))) return e;
+            // stretch codes (4 words per redo word), 16 rows of padding (box_kernel reads a wave's rows without
+            // clamping), redo bits
+            if (int e = ds->cull.ensure(((size_t)5 * job.nframes * tg.row_count + 64) * words * sizeof(uint32_t))) return e;
             li.cull_buf = (uint32_t *)ds->cull.p;
         }
         r = nt_launch_box(li, cam, tg);

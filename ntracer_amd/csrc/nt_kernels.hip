@@ -686,12 +686,12 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         // what box_cull_kernel found out about the wave's rows, four bits a row (row rr in bits 4rr..4rr+3)
         static_assert(R <= 16, "sixteen row codes to a qword");
         unsigned long long rowcodes = 0ull;
+        // (rows past the last one read on into the table's padding: `valid` masks them out)
+        const uint32_t *cp = tg.cull + ((size_t)blockIdx.z * tg.row_count + row0) * tg.cull_words + (blockIdx.x >> 3);
+        const int nibble = 4 * (blockIdx.x & 7);
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            const int row = row0 + rr < tg.row_count ? row0 + rr : tg.row_count - 1;
-            const uint32_t codes = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 3)];
-            rowcodes |= (unsigned long long)((codes >> (4 * (blockIdx.x & 7))) & 15u) << (4 * rr);
-        }
+        for (int rr = 0; rr < R; ++rr)
+            rowcodes |= (unsigned long long)((cp[rr * tg.cull_words] >> nibble) & 15u) << (4 * rr);
         // Background rows need |dir|^2 only to ~2^-19 (see the guard below): as a quadratic in sy,
         //   |base - up*sy|^2 = base.base - 2*sy*(base.up) + sy^2*(up.up),
         // it costs two fma per row instead of the N-1 other components and their squares.  Its absolute error is
@@ -3311,7 +3311,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         tg.redo_words = (ncols + 31) / 32;
         tg.cull_words = 4 * tg.redo_words;
         const long long threads = (long long)tg.row_count * tg.redo_words * 32;
-        tg.redo = li.cull_buf + (size_t)li.nframes * tg.row_count * tg.cull_words;
+        tg.redo = li.cull_buf + ((size_t)li.nframes * tg.row_count + 16) * tg.cull_words;        // 16 rows of padding after the codes
         hipLaunchKernelGGL(box_cull_kernel<N>, dim3((unsigned)((threads + 255) / 256), 1, (unsigned)li.nframes), dim3(256), 0,
                            (hipStream_t)li.stream, cf, tg, li.cull_buf, ncols);
         tg.cull = li.cull_buf;
