@@ -477,6 +477,20 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         tg.plain_bits = f.plain_bits;
         tg.plain_maxval = f.plain_maxval;
         for (int k = 0; k < 3; ++k) tg.plain_mul[k] = f.plain_mul[k];
+        tg.plain_sel = 0;
+        if (f.plain_bits == 8 && ((f.plain_mul[0] | f.plain_mul[1] | f.plain_mul[2]) & ~0x01010101u) == 0) {
+            // byte b of the MSB-first pixel word holds the component whose multiplier has bit 8b set; memory byte k is
+            // byte 3-k of that word (or byte k when the pixel's bytes are reversed)
+            uint32_t sel = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int b = f.reversed ? k : 3 - k;
+                uint32_t pick = 0x0c;                                            // constant 0
+                if ((f.plain_mul[0] >> (8 * b)) & 1u) pick = 4;                  // byte 0 of src0: R
+                else if (((f.plain_mul[1] | f.plain_mul[2]) >> (8 * b)) & 1u) pick = 0;     // byte 0 of src1: G = B
+                sel |= pick << (8 * k);
+            }
+            tg.plain_sel = sel;
+        }
         for (int k = 0; k < 3; ++k) tg.plain_f32[k] = f.plain_f32[k];
         tg.bpp = f.bpp;
         tg.reversed = f.reversed;

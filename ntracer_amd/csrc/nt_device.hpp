@@ -38,6 +38,9 @@ struct NtTarget {
     // plain RGB layouts in one dword (RGBX8, BGRA8, ...): plain_bits != 0, and component k goes to the fields
     // plain_mul[k] marks (a quantised component times plain_mul[k] is that component shifted into all of them)
     uint32_t plain_bits, plain_maxval, plain_mul[3];
+    // ... and for 8-bit fields on byte boundaries (RGBX8, BGRA8, ...): the v_perm_b32 selector that builds the dword as it
+    // lies in memory from (src0 = quantised R, src1 = quantised G = B); 0 when the layout is not of that kind
+    uint32_t plain_sel;
     int plain_f32[3];         // 12-byte pixels of three fp32 channels that are plain components: component of float k; else -1
     int width, height;        // view size: set_view_size(w,h) (tracer.hpp:65-69)
     float half_w, half_h, fovI;

@@ -289,6 +289,11 @@ __device__ __forceinline__ uint32_t plain_quantize(const NtTarget &tg, float v) 
     return quantize(v, tg.plain_maxval, tg.plain_bits);
 }
 __device__ __forceinline__ void emit_plain(const NtTarget &tg, const PixelRef &pr, uint32_t qr, uint32_t qgb) {
+    if (tg.plain_sel != 0u) {
+        // 8-bit fields on byte boundaries: one v_perm_b32 puts the two values where they go, in memory order
+        *reinterpret_cast<uint32_t *>(tg.dest + pr.offset) = __builtin_amdgcn_perm(qr, qgb, tg.plain_sel);
+        return;
+    }
     const uint32_t w = qr * tg.plain_mul[0] + qgb * (tg.plain_mul[1] + tg.plain_mul[2]);
     *reinterpret_cast<uint32_t *>(tg.dest + pr.offset) = tg.reversed ? w : bswap32(w);
 }
