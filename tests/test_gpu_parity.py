@@ -138,6 +138,27 @@ def test_box_stress_cameras_bytes_and_floats_equal_oracle(n):
             assert np.array_equal(got.view(np.uint32), osc.colors_at(xs, ys, w, h).view(np.uint32)), (n, k)
 
 
+@pytest.mark.parametrize("rev", [False, True])
+def test_box_byte_orders_of_packed_rgb(rev):
+    """RGBX / BGRX / XRGB / XBGR / RGB with a repeated component, straight and byte-reversed: the byte-permute packing
+    of the specialised BoxScene kernel against the oracle's generic packer."""
+    layouts = [[(8, 1, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0, 0, 0)],
+               [(8, 0, 0, 1), (8, 0, 1, 0), (8, 1, 0, 0), (8, 0, 0, 0)],
+               [(8, 0, 0, 0), (8, 1, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1)],
+               [(8, 0, 0, 0), (8, 0, 0, 1), (8, 0, 1, 0), (8, 1, 0, 0)],
+               [(8, 1, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 1, 0, 0)],
+               [(8, 0, 1, 0), (8, 0, 0, 0), (8, 0, 0, 0), (8, 0, 1, 0)]]
+    g = fx.load("box_n6_1920x1080")
+    w, h = 448, 40
+    sc = tracern.BoxScene(6)
+    for k, chans in enumerate(layouts):
+        f = 20 * k + 3
+        sc._set_camera_arrays(g["origins"][f], g["axes"][f])
+        img = render_host(sc, fmt_of(w, h, chans, 0, rev))
+        ref = ob.OracleScene(6, g["origins"][f], g["axes"][f]).render(w, h, chans, reversed_=rev, threads=7)
+        assert np.array_equal(img, ref), (k, rev, int((img != ref).sum()))
+
+
 def test_box_wide_rows_and_the_kernel_without_stretch_codes(monkeypatch):
     """More than 2048 pixels a row (two words of redo bits, several of stretch codes), a width that is not a multiple
     of 64, and the same frames through the general kernel (NTRACER_BOX_CULL=0: no pre-kernel, no second pass)."""
