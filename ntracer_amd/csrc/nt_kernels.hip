@@ -666,6 +666,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
     const int row0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * R;
     if (PLAIN) {
         // ---- packed RGB, at most 10 bits a channel: the lean loop ----
+        if (row0 >= tg.row_count) return;             // (also keeps the row-code reads below inside the table's padding)
         // Row bookkeeping is done once, one row per lane (lane l <-> row row0 + l), and read back with v_readlane:
         // sy, up[0]*sy, the row's byte offset, whether the row exists.  Every lane stays active for that -- lanes past
         // the right edge redo the last pixel (the same dword, the same value) instead of leaving.
