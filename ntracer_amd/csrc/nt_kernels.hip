@@ -492,6 +492,21 @@ __device__ __forceinline__ void box_classify(const float (&o)[N], const float (&
     x = hit ? vK : v[0];
 }
 
+// The part of box_classify that box_resolve needs: entry times into the unit cube, the last of them, its axis.
+template <int N>
+__device__ __forceinline__ void box_entries(const float (&o)[N], const float (&v)[N], float (&near)[N], float &tn, float &vK) {
+    tn = -INFINITY;
+    vK = 0.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float inv = __builtin_amdgcn_rcpf(v[j]);
+        const float nr = fminf((-1.0f - o[j]) * inv, (1.0f - o[j]) * inv);
+        near[j] = nr;
+        vK = nr > tn ? v[j] : vK;
+        tn = fmaxf(tn, nr);
+    }
+}
+
 // The unclear lanes of a wave, resolved with the reference's own arithmetic -- but only the part of it that can
 // matter.  With near[], tn, vK from box_classify (approximate; the margins absorb that):
 //   T = { i : (tn - near_i)*|v_K| <= m }   the faces that can still be the reference's answer: any other face is
@@ -551,17 +566,25 @@ __device__ __forceinline__ void box_resolve(const float (&o)[N], const float (&v
 // PLAIN: the format is known to be plain_rgb with at most 10 bits per channel (the launcher checks).
 // DEFER: a wave with an unclear lane writes nothing and returns false (the caller hands the stretch to box_redo_kernel),
 // which keeps the resolving code -- and its registers -- out of the kernel every other wave runs.
-template <int N, bool PLAIN, bool DEFER = false>
+// REDO (box_redo_kernel): no sorting into clear and unclear -- box_resolve is complete by itself (a clear hit is T = C =
+// {K}; a clear miss fails at a coordinate of C), and in a stretch that is here because of its unclear lanes the
+// sorting of the others saves nothing.
+template <int N, bool PLAIN, bool DEFER = false, bool REDO = false>
 __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
                                           const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true) {
     // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
-    const bool maybe = rowhit && box_may_hit(N, dots, sx, sy, sq);
+    const bool maybe = REDO || (rowhit && box_may_hit(N, dots, sx, sy, sq));
     float r, g, b;
     bool hit = false, unclear = false;
     float x = dir[0];
 #ifndef NT_EXP_NOCLASSIFY
     float near[N], tn = 0.0f, vK = 0.0f;
-    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) box_classify<N>(org, dir, margin, maybe, hit, unclear, x, near, tn, vK);
+    if (REDO) {
+        box_entries<N>(org, dir, near, tn, vK);
+        unclear = true;
+    } else if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+        box_classify<N>(org, dir, margin, maybe, hit, unclear, x, near, tn, vK);
+    }
     // unclear lanes: the reference's arithmetic on the faces and coordinates still in question; a lane without a
     // usable entry time (origin on or inside the cube, NaN) keeps the whole wave on box_color's full evaluation
     if (DEFER) {
@@ -898,7 +921,7 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
         float sq = dir[0] * dir[0];
 #pragma unroll
         for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-        box_pixel<N, true, false>(tg, pr, org, dir, sq, dots, sx, sy, margin);
+        box_pixel<N, true, false, true>(tg, pr, org, dir, sq, dots, sx, sy, margin);
     }
 }
 
