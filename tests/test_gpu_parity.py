@@ -95,6 +95,13 @@ def _stress_cameras(n, rng):
             q = eye + 1e-7 * rng.standard_normal((n, n))     # almost axis-aligned: grazing rays
         elif k == 2:
             q = eye[rng.permutation(n)]
+        elif k == 3:
+            q = q.copy()
+            q[1] = q[1] + 0.8 * q[2] + 0.3 * q[0]            # `up` far from orthogonal: no quadratic |dir|^2 shortcut
+        elif k == 4:
+            q = q.copy()
+            q[0] = 3.0 * q[0]                                # stretched `right`
+            q[1] = 0.0 * q[1]                                # ... and no `up` at all: every row the same
         q = np.ascontiguousarray(q, np.float32)
         for dist in (0.3, 1.0, 1.0000001, 1.7, 3.0, 9.0, 60.0):
             back = -q[2] * np.float32(dist)                  # look at the centre from `dist` away ...
