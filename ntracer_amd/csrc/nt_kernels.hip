@@ -946,10 +946,9 @@ template <int N>
 __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarget tg, uint32_t *out, int ncols) {
     float org[N], right[N], up[N], fwd[N];
     load_camera<N>(cam, org, right, up, fwd);
-    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    const int rw = i >> 5;                               // (row, 32 stretches): the same for a half-wave
-    const int word = rw % tg.redo_words, row = rw / tg.redo_words;
-    const int col = word * 32 + (i & 31);
+    // a half-wave = 32 stretches of one row: blockIdx.x = which 32, blockIdx.y = which 8 rows
+    const int word = (int)blockIdx.x, row = (int)blockIdx.y * 8 + (int)(threadIdx.x >> 5);
+    const int col = word * 32 + (int)(threadIdx.x & 31);
     uint32_t code = 0u;
     if (row < tg.row_count && col < ncols) {
         const int orow = tg.row_begin + row;
@@ -978,16 +977,22 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
             const float pa = vc[j] + g[j], qa = -h - org[j];
             const float pb = vc[j] - g[j], qb = h - org[j];
             const float ra = qa * __builtin_amdgcn_rcpf(pa), rb = qb * __builtin_amdgcn_rcpf(pb);
-            if (pa > 0.0f) tlo = fmaxf(tlo, ra);
-            else if (pa < 0.0f) thi = fminf(thi, ra);
-            else if (pa == 0.0f && qa > 0.0f) dead = true;
-            if (pb > 0.0f) thi = fminf(thi, rb);
-            else if (pb < 0.0f) tlo = fmaxf(tlo, rb);
-            else if (pb == 0.0f && qb < 0.0f) dead = true;
+            // pa*tau >= qa bounds tau from below when pa > 0, from above when pa < 0; pb*tau <= qb the other way round
+            // (a NaN -- 0*inf -- drops out of fmaxf / fminf)
+            const float lo_a = pa > 0.0f ? ra : -INFINITY, hi_a = pa < 0.0f ? ra : INFINITY;
+            const float hi_b = pb > 0.0f ? rb : INFINITY, lo_b = pb < 0.0f ? rb : -INFINITY;
+            tlo = fmaxf(tlo, fmaxf(lo_a, lo_b));
+            thi = fminf(thi, fminf(hi_a, hi_b));
+            dead = dead || (pa == 0.0f && qa > 0.0f) || (pb == 0.0f && qb < 0.0f);
             // the middle ray's entry into slab j (any K is verified below, so accuracy only matters for the yield)
             const float nr = ((vc[j] < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc[j]);
             tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);         // second-to-last entry
-            if (nr > tn) { tn = nr; vK = vc[j]; gK = g[j]; oK = org[j]; K = j; }
+            const bool later = nr > tn;
+            vK = later ? vc[j] : vK;
+            gK = later ? g[j] : gK;
+            oK = later ? org[j] : oK;
+            K = later ? j : K;
+            tn = fmaxf(tn, nr);
         }
         if (!(dead || tlo > thi)) {                      // a NaN keeps the stretch
             code = 15u;
@@ -3339,9 +3344,8 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         const int ncols = (tg.width + 63) / 64;
         tg.redo_words = (ncols + 31) / 32;
         tg.cull_words = 4 * tg.redo_words;
-        const long long threads = (long long)tg.row_count * tg.redo_words * 32;
         tg.redo = li.cull_buf + ((size_t)li.nframes * tg.row_count + 16) * tg.cull_words;        // 16 rows of padding after the codes
-        hipLaunchKernelGGL(box_cull_kernel<N>, dim3((unsigned)((threads + 255) / 256), 1, (unsigned)li.nframes), dim3(256), 0,
+        hipLaunchKernelGGL(box_cull_kernel<N>, dim3((unsigned)tg.redo_words, (unsigned)((tg.row_count + 7) / 8), (unsigned)li.nframes), dim3(256), 0,
                            (hipStream_t)li.stream, cf, tg, li.cull_buf, ncols);
         tg.cull = li.cull_buf;
     }
