@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
     }
     if ((!PLAIN && tg.colors_out) || ROWS == 1) {
-        // one pixel per lane: probe mode (listed pixels), and n > 8
+        // one pixel per lane: probe mode (listed pixels)
         const PixelRef pr = locate_pixel<64, 4>(tg, tid & 63, tid >> 6, tid);
         if (!pr.valid) return;
         // flat_origin_ray_source::operator() (tracer.hpp:71-75), as primary_dir, with the normalisation split off
