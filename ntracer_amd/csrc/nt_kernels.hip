@@ -843,14 +843,19 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
     float base[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
+    // the stretch codes of the wave's rows, fetched together ahead of the loop (only "culled or not" is used here)
+    uint32_t live = ~0u;
+    if (tg.cull) {
+        if (row0 >= tg.row_count) return;               // (keeps the reads inside the table's padding)
+        const uint32_t *cp = tg.cull + ((size_t)blockIdx.z * tg.row_count + row0) * tg.cull_words + (blockIdx.x >> 3);
+        live = 0u;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) live |= (((cp[rr * tg.cull_words] >> (4 * (blockIdx.x & 7))) & 15u) != 0u ? 1u : 0u) << rr;
+    }
     for (int rr = 0; rr < R; ++rr) {
         const int row = row0 + rr;                      // relative to row_begin; the same for the whole wave
         if (row >= tg.row_count) return;
-        bool rowhit = true;
-        if (tg.cull) {
-            const uint32_t codes = tg.cull[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (blockIdx.x >> 3)];
-            rowhit = ((codes >> (4 * (blockIdx.x & 7))) & 15u) != 0u;
-        }
+        const bool rowhit = (live >> rr) & 1u;
         const int orow = tg.row_begin + row;
         int y = orow;
         if (tg.band_world > 1) {
