@@ -14,6 +14,7 @@
  *
  * Build:  make -C oracle      (gcc -O2 -ffp-contract=off, no -ffast-math)
  */
+#define _POSIX_C_SOURCE 200809L      /* clock_gettime, sysconf under -std=c99 */
 #include "ntracer_oracle.h"
 
 #include <float.h>
@@ -21,6 +22,8 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #define MAXD NTO_MAX_DIM
 #define ROUNDING_FUZZ (FLT_EPSILON * 10.0f)       /* tracer.hpp:25 */
@@ -762,10 +765,24 @@ typedef struct {
     int w, h, pitch, nchannels, reversed, bpp;
     const nto_channel *ch;
     unsigned int chunk;          /* atomic */
-    nto_counters *counters;      /* per thread */
+    int want_counters;
 } job_t;
 
-typedef struct { job_t *job; nto_counters counters; } worker_t;
+/* blocking_renderer (render.cpp:769-838): `threads` workers that live as long as the renderer and sleep on
+   start_cond between frames; the caller draws too and then waits on finish_cond. */
+struct nto_renderer {
+    pthread_mutex_t mut;
+    pthread_cond_t start_cond, finish_cond;
+    int nworkers;
+    pthread_t *workers;
+    nto_counters *counters;      /* [nworkers + 1], the caller's last */
+    unsigned int job;            /* frame number, bumped under `mut` (render.cpp:896) */
+    unsigned int busy_threads;
+    int quit;
+    job_t cur;
+};
+
+typedef struct { nto_renderer *r; int index; } worker_arg_t;
 
 static void worker_draw(job_t *r, nto_counters *c) {
     int chunks_x = (r->w + RENDER_CHUNK_SIZE - 1) / RENDER_CHUNK_SIZE;
@@ -791,40 +808,152 @@ static void worker_draw(job_t *r, nto_counters *c) {
     }
 }
 
-static void *worker_main(void *arg) {
-    worker_t *w = (worker_t *)arg;
-    worker_draw(w->job, w->job->counters ? &w->counters : NULL);
-    return NULL;
+/* wait_for_job (render.cpp:790-801); `mut` held */
+static int wait_for_job(nto_renderer *r) {
+    unsigned int finished;
+    do {
+        if (r->quit) return 0;
+        finished = r->job;
+        pthread_cond_wait(&r->start_cond, &r->mut);
+    } while (finished == r->job);
+    return !r->quit;
 }
 
-int nto_render(const nto_scene *s, uint8_t *dest, int w, int h, int pitch, int nchannels, const nto_channel *ch,
-               int reversed, int threads, nto_counters *counters) {
+/* blocking_worker (render.cpp:803-827) */
+static void *blocking_worker(void *arg) {
+    worker_arg_t *wa = (worker_arg_t *)arg;
+    nto_renderer *r = wa->r;
+    nto_counters *c = &r->counters[wa->index];
+    free(wa);
+    pthread_mutex_lock(&r->mut);
+    if (!r->busy_threads && !wait_for_job(r)) { pthread_mutex_unlock(&r->mut); return NULL; }
+    pthread_mutex_unlock(&r->mut);
+    for (;;) {
+        worker_draw(&r->cur, r->cur.want_counters ? c : NULL);
+        pthread_mutex_lock(&r->mut);
+        if (--r->busy_threads == 0) pthread_cond_signal(&r->finish_cond);
+        if (!wait_for_job(r)) { pthread_mutex_unlock(&r->mut); return NULL; }
+        pthread_mutex_unlock(&r->mut);
+    }
+}
+
+/* blocking_renderer::blocking_renderer (render.cpp:829-838): threads < 0 => hardware_concurrency() - 1 */
+nto_renderer *nto_renderer_create(int threads) {
+    if (threads < 0) {
+        long hc = sysconf(_SC_NPROCESSORS_ONLN);
+        threads = hc > 1 ? (int)hc - 1 : 0;
+    }
+    nto_renderer *r = (nto_renderer *)calloc(1, sizeof(*r));
+    if (!r) return NULL;
+    pthread_mutex_init(&r->mut, NULL);
+    pthread_cond_init(&r->start_cond, NULL);
+    pthread_cond_init(&r->finish_cond, NULL);
+    r->counters = (nto_counters *)calloc((size_t)threads + 1, sizeof(nto_counters));
+    r->workers = (pthread_t *)calloc((size_t)threads + 1, sizeof(pthread_t));
+    for (int i = 0; i < threads; ++i) {
+        worker_arg_t *wa = (worker_arg_t *)malloc(sizeof(*wa));
+        wa->r = r;
+        wa->index = i;
+        if (pthread_create(&r->workers[i], NULL, blocking_worker, wa) != 0) { free(wa); break; }
+        r->nworkers = i + 1;
+    }
+    return r;
+}
+
+int nto_renderer_threads(const nto_renderer *r) { return r ? r->nworkers + 1 : 0; }
+
+/* blocking_renderer::~blocking_renderer (render.cpp:840-851) */
+void nto_renderer_destroy(nto_renderer *r) {
+    if (!r) return;
+    pthread_mutex_lock(&r->mut);
+    r->quit = 1;
+    pthread_cond_broadcast(&r->start_cond);
+    pthread_mutex_unlock(&r->mut);
+    for (int i = 0; i < r->nworkers; ++i) pthread_join(r->workers[i], NULL);
+    pthread_mutex_destroy(&r->mut);
+    pthread_cond_destroy(&r->start_cond);
+    pthread_cond_destroy(&r->finish_cond);
+    free(r->counters);
+    free(r->workers);
+    free(r);
+}
+
+/* obj_BlockingRenderer_render (render.cpp:853-909) */
+int nto_renderer_render(nto_renderer *r, const nto_scene *s, uint8_t *dest, int w, int h, int pitch, int nchannels,
+                        const nto_channel *ch, int reversed, nto_counters *counters) {
     long bits = 0;
     for (int k = 0; k < nchannels; ++k) bits += ch[k].bit_size;
-    if (bits > 128 || w < 1 || h < 1) return -1;
+    if (!r || bits > 128 || w < 1 || h < 1) return -1;
     job_t job;
     job.s = s; job.dest = dest; job.w = w; job.h = h; job.nchannels = nchannels; job.reversed = reversed;
-    job.ch = ch; job.bpp = (int)((bits + 7) / 8); job.chunk = 0; job.counters = counters;
+    job.ch = ch; job.bpp = (int)((bits + 7) / 8); job.chunk = 0; job.want_counters = counters != NULL;
     job.pitch = pitch ? pitch : w * job.bpp;
     if (job.pitch < w * job.bpp) return -1;
-    if (threads < 0) threads = 0;
-    worker_t *ws = (worker_t *)calloc((size_t)threads + 1, sizeof(worker_t));
-    pthread_t *th = (pthread_t *)calloc((size_t)threads + 1, sizeof(pthread_t));
-    for (int i = 0; i <= threads; ++i) ws[i].job = &job;
-    for (int i = 0; i < threads; ++i) pthread_create(&th[i], NULL, worker_main, &ws[i]);
-    worker_main(&ws[threads]);
-    for (int i = 0; i < threads; ++i) pthread_join(th[i], NULL);
+    pthread_mutex_lock(&r->mut);
+    if (r->busy_threads) { pthread_mutex_unlock(&r->mut); return -2; }      /* already_running_error */
+    if (counters) memset(r->counters, 0, ((size_t)r->nworkers + 1) * sizeof(nto_counters));
+    r->cur = job;
+    r->busy_threads = (unsigned int)r->nworkers;
+    pthread_cond_broadcast(&r->start_cond);
+    ++r->job;
+    pthread_mutex_unlock(&r->mut);
+
+    worker_draw(&r->cur, counters ? &r->counters[r->nworkers] : NULL);
+
+    pthread_mutex_lock(&r->mut);
+    while (r->busy_threads) pthread_cond_wait(&r->finish_cond, &r->mut);
+    pthread_mutex_unlock(&r->mut);
     if (counters) {
         memset(counters, 0, sizeof(*counters));
-        for (int i = 0; i <= threads; ++i) {
-            const uint64_t *src = (const uint64_t *)&ws[i].counters;
+        for (int i = 0; i <= r->nworkers; ++i) {
+            const uint64_t *src = (const uint64_t *)&r->counters[i];
             uint64_t *dst = (uint64_t *)counters;
             for (size_t k = 0; k < sizeof(nto_counters) / sizeof(uint64_t); ++k) dst[k] += src[k];
         }
     }
-    free(ws);
-    free(th);
     return 0;
+}
+
+/* one renderer for the call: BlockingRenderer(threads).render(dest, format, scene) */
+int nto_render(const nto_scene *s, uint8_t *dest, int w, int h, int pitch, int nchannels, const nto_channel *ch,
+               int reversed, int threads, nto_counters *counters) {
+    if (threads < 0) threads = 0;
+    nto_renderer *r = nto_renderer_create(threads);
+    if (!r) return -1;
+    int rc = nto_renderer_render(r, s, dest, w, h, pitch, nchannels, ch, reversed, counters);
+    nto_renderer_destroy(r);
+    return rc;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* The RotatingCamera loop of scripts/polytope.py:522-556 around one renderer: frame f is drawn with camera
+   (origins[f % ncams], axes[f % ncams]) into the same `dest`; the workers sleep on start_cond between frames.
+   Stops after `nframes` frames or once `max_seconds` (> 0) have passed; seconds_out[f] = wall time of frame f.
+   Returns the number of frames drawn, or a negative error. */
+int nto_renderer_render_frames(nto_renderer *r, const nto_scene *s, uint8_t *dest, int w, int h, int pitch, int nchannels,
+                               const nto_channel *ch, int reversed, int nframes, int ncams, const float *origins,
+                               const float *axes, double max_seconds, double *seconds_out) {
+    if (!r || nframes < 0 || ncams < 1) return -1;
+    nto_scene sc = *s;
+    const int n = s->n;
+    const double t_begin = now_s();
+    int f = 0;
+    for (; f < nframes; ++f) {
+        sc.origin = origins + (size_t)(f % ncams) * n;
+        sc.axes = axes + (size_t)(f % ncams) * n * n;
+        const double t0 = now_s();
+        int rc = nto_renderer_render(r, &sc, dest, w, h, pitch, nchannels, ch, reversed, NULL);
+        if (rc) return rc;
+        const double t1 = now_s();
+        if (seconds_out) seconds_out[f] = t1 - t0;
+        if (max_seconds > 0 && t1 - t_begin > max_seconds) { ++f; break; }
+    }
+    return f;
 }
 
 /* ---------------- per-stage entry points (ntracer_body.hpp:1412-1496) ---------------- */

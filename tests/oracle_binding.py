@@ -63,6 +63,19 @@ def lib():
         _LIB.nto_render.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.POINTER(Channel), C.c_int, C.c_int, C.POINTER(Counters)]
         _LIB.nto_render.restype = C.c_int
+        _LIB.nto_renderer_create.argtypes = [C.c_int]
+        _LIB.nto_renderer_create.restype = C.c_void_p
+        _LIB.nto_renderer_destroy.argtypes = [C.c_void_p]
+        _LIB.nto_renderer_destroy.restype = None
+        _LIB.nto_renderer_threads.argtypes = [C.c_void_p]
+        _LIB.nto_renderer_threads.restype = C.c_int
+        _LIB.nto_renderer_render.argtypes = [C.c_void_p, C.POINTER(Scene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(Channel), C.c_int, C.POINTER(Counters)]
+        _LIB.nto_renderer_render.restype = C.c_int
+        _LIB.nto_renderer_render_frames.argtypes = [C.c_void_p, C.POINTER(Scene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.POINTER(Channel), C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_double,
+                                                    C.POINTER(C.c_double)]
+        _LIB.nto_renderer_render_frames.restype = C.c_int
         _LIB.nto_kd_intersects.argtypes = [C.POINTER(Scene), f32p, f32p, C.c_float, C.c_float, C.c_int, C.c_int,
                                            f32p, i32p, i32p, i32p, f32p, f32p, i32p]
         _LIB.nto_kd_intersects.restype = C.c_int
@@ -199,6 +212,46 @@ class OracleScene:
         out = np.zeros(self.n, np.float32)
         lib().nto_primary_dir(C.byref(self.s), x, y, w, h, out.ctypes.data_as(f32p))
         return out
+
+
+class OracleRenderer:
+    """blocking_renderer of the reference (render.cpp:769-851): worker threads that persist between frames."""
+
+    def __init__(self, threads=-1):
+        self._h = lib().nto_renderer_create(int(threads))
+        assert self._h
+        self.threads = lib().nto_renderer_threads(self._h)      # workers + the caller
+
+    def close(self):
+        if self._h:
+            lib().nto_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def render(self, scene, w, h, channels, pitch=0, reversed_=False, counters=False):
+        ch, bpp = make_channels(channels)
+        pitch = pitch or w * bpp
+        buf = np.zeros((h, pitch), np.uint8)
+        c = Counters()
+        r = lib().nto_renderer_render(self._h, C.byref(scene.s), buf.ctypes.data, w, h, pitch, len(ch), ch, int(bool(reversed_)),
+                                      C.byref(c) if counters else None)
+        assert r == 0
+        return (buf, c.as_dict()) if counters else buf
+
+    def render_frames(self, scene, w, h, channels, origins, axes, nframes, max_seconds=0.0):
+        """`nframes` frames of the camera sequence inside ONE C call (the last frame stays in the returned buffer);
+        returns (buffer, seconds per frame)."""
+        ch, bpp = make_channels(channels)
+        buf = np.zeros((h, w * bpp), np.uint8)
+        o = _f(origins).reshape(-1, scene.n)
+        a = _f(axes).reshape(len(o), scene.n, scene.n)
+        secs = (C.c_double * nframes)()
+        done = lib().nto_renderer_render_frames(self._h, C.byref(scene.s), buf.ctypes.data, w, h, 0, len(ch), ch, 0, nframes, len(o),
+                                                o.ctypes.data_as(f32p), a.ctypes.data_as(f32p), float(max_seconds), secs)
+        assert done >= 0
+        return buf, np.array(secs[:done])
 
 
 def channels_from_table(tab):

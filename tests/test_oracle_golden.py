@@ -180,6 +180,32 @@ def test_threaded_render_is_deterministic():
     assert np.array_equal(a, b)
 
 
+def test_persistent_renderer_reuses_its_workers_across_frames():
+    """blocking_renderer (render.cpp:769-851): the workers sleep on start_cond between frames.  Many frames through one
+    renderer -- one at a time and inside one C call -- give the bytes of fresh single-frame renders."""
+    g = fx.load("box_n6_1920x1080")
+    sc = ob.OracleScene(6, g["origins"][0], g["axes"][0])
+    r = ob.OracleRenderer(3)
+    assert r.threads == 4
+    w, h = 131, 77
+    for f in (0, 11, 97, 11):
+        sc.set_camera(g["origins"][f], g["axes"][f])
+        assert np.array_equal(r.render(sc, w, h, fx.RGBX8), sc.render(w, h, fx.RGBX8, threads=0)), f
+    buf, secs = r.render_frames(sc, w, h, fx.RGBX8, g["origins"][:40], g["axes"][:40], 100)
+    assert len(secs) == 100 and (secs > 0).all()
+    sc.set_camera(g["origins"][99 % 40], g["axes"][99 % 40])
+    assert np.array_equal(buf, sc.render(w, h, fx.RGBX8, threads=0))
+    # the time limit stops the loop early
+    _, secs = r.render_frames(sc, w, h, fx.RGBX8, g["origins"][:40], g["axes"][:40], 100000, max_seconds=0.05)
+    assert 1 <= len(secs) < 100000
+    r.close()
+    # a renderer with no workers draws everything on the caller
+    r0 = ob.OracleRenderer(0)
+    assert r0.threads == 1
+    assert np.array_equal(r0.render(sc, w, h, fx.RGBX8), sc.render(w, h, fx.RGBX8, threads=2))
+    r0.close()
+
+
 @pytest.mark.parametrize("name", ["cell600_n4", "orthoplex5_n5", "simplex10_n10"])
 def test_pruned_walk_is_pixel_identical_on_the_oracle(name):
     """nto_scene.prune_beyond_hit (what the HIP kernels do unless strict_reference is set) against the
