@@ -1,19 +1,37 @@
 """Build libntracer_hip.so in-tree:  python -m ntracer_amd.build
 
-hipcc cross-compiles gfx950 code objects without a GPU.  -ffp-contract=off is part of the
-arithmetic contract with the oracle (see csrc/nt_kernels.hip); -fno-slp-vectorize because packing pairs of
-independent fp32 operations into v_pk_* costs more register shuffling than it saves here (measured: 2-4 %)."""
+hipcc cross-compiles gfx950 code objects without a GPU.  The kernels are templates over the dimension; every
+dimension is its own translation unit (csrc/nt_inst_box.hip and csrc/nt_inst_composite.hip with -DNT_INST_N=3..10),
+compiled in parallel into build/*.o and linked with the host side.  -ffp-contract=off is part of the arithmetic
+contract with the oracle (see csrc/nt_pixel.hpp); -fno-slp-vectorize because packing pairs of independent fp32
+operations into v_pk_* costs more register shuffling than it saves here (measured: 2-4 %)."""
+import concurrent.futures
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", "nt_api.cpp"), os.path.join(HERE, "csrc", "nt_builder.cpp"), os.path.join(HERE, "csrc", "nt_kernels.hip")]
-HDR = [os.path.join(HERE, "csrc", "nt_device.hpp"), os.path.join(HERE, "..", "include", "ntracer_hip.h")]
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libntracer_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-fno-slp-vectorize", "-Wall",
+DIMS = range(3, 11)
+HDR = [os.path.join(CSRC, h) for h in ("nt_device.hpp", "nt_pixel.hpp", "nt_box.hpp", "nt_composite.hpp")] + \
+      [os.path.join(HERE, "..", "include", "ntracer_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-function"]
+EXTRA = os.environ.get("NTRACER_HIPCC_FLAGS", "").split()         # ablation builds (-DNT_EXP_...)
+
+
+def units():
+    """(object name, source, extra flags)"""
+    u = [("nt_api", "nt_api.cpp", []), ("nt_builder", "nt_builder.cpp", []), ("nt_launch", "nt_launch.cpp", []),
+         ("nt_var", "nt_var.hip", [])]
+    for n in DIMS:
+        u.append(("nt_box_%d" % n, "nt_inst_box.hip", ["-DNT_INST_N=%d" % n]))
+        u.append(("nt_composite_%d" % n, "nt_inst_composite.hip", ["-DNT_INST_N=%d" % n]))
+    return u
 
 
 def hipcc():
@@ -23,23 +41,48 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def up_to_date():
-    if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(p) <= t for p in SRC + HDR)
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
-        return OUT
-    cmd = [hipcc()] + FLAGS + SRC + ["-o", OUT + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+def _flag_tag():
+    return hashlib.sha1(" ".join(FLAGS + EXTRA).encode()).hexdigest()[:8]
+
+
+def build(force=False, verbose=False, out=None):
+    out = out or OUT
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    tag = _flag_tag()
+    jobs = []
+    objs = []
+    for name, src, extra in units():
+        o = os.path.join(OBJ, "%s.%s.o" % (name, tag))
+        objs.append(o)
+        s = os.path.join(CSRC, src)
+        if force or _stale(o, [s] + HDR):
+            jobs.append([cc] + FLAGS + EXTRA + extra + ["-c", s, "-o", o])
+    if jobs:
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        # the composite units are the long ones (~40 s each): start them first
+        jobs.sort(key=lambda c: 0 if "nt_inst_composite.hip" in c[-3] else 1)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(out, objs):
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", out + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    print(build(force="--force" in sys.argv, verbose=True, out=args[0] if args else None))

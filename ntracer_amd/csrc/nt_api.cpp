@@ -4,7 +4,7 @@
 //   ImageFormat/Channel validation      src/render.cpp:120-164, 187-209, 249-288
 //   renderer frame loop and protocol    src/render.cpp:853-923 (busy / lock / abort)
 //   box_scene / composite_scene state   src/tracer.hpp:83-123, 1710-1748
-// The per-pixel work itself is in nt_kernels.hip.  There is NO CPU fallback: without a HIP
+// The per-pixel work itself is in nt_box.hpp / nt_composite.hpp / nt_var.hip.  There is NO CPU fallback: without a HIP
 // device every render entry point fails with NT_E_DEVICE.
 #include <hip/hip_runtime_api.h>
 
@@ -529,7 +529,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         NtCompositeDev c;
         fill_composite(s, ds, c, job.stats);
         // closest-hit walks drop subtrees beyond the current hit unless the caller (or NTRACER_STRICT_REFERENCE=1)
-        // asks for the reference's exact walk; the pixels are the same (nt_beyond_hit in nt_kernels.hip)
+        // asks for the reference's exact walk; the pixels are the same (nt_beyond_hit in nt_composite.hpp)
         const char *es = getenv("NTRACER_STRICT_REFERENCE");
         const bool env_strict = es && atoi(es) != 0;
         // ... and never for scenes with Solids: trees from the reference's own builder leave solids out of some cells

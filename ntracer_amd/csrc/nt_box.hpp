@@ -1,0 +1,752 @@
+// nt_box.hpp -- BoxScene kernels for compile-time N (fixed_geometry.hpp -> registers):
+//   box_cull_kernel<N> -> box_kernel<N,PLAIN,ROWS> -> box_redo_kernel<N>      box_scene::calculate_color (src/tracer.hpp:101-152)
+// fused with process_pixel's conversion and packing (nt_pixel.hpp), so the only HBM traffic of a frame is the packed
+// framebuffer.  Instantiated per N by nt_inst_box.hip.
+#pragma once
+#include "nt_pixel.hpp"
+
+namespace {
+
+// box_scene::calculate_color + hypercube_intersects (tracer.hpp:101-152).
+//
+// The reference tries the entry face of every axis i in ascending order; face i is the hit when
+// dist_i = (s_i - o_i)/d_i > 0 and |o_j + d_j*dist_i| <= 1+FUZZ for all j != i.  That predicate is evaluated
+// here bit for bit, but only for the faces that can satisfy it:
+//   1. a ray whose distance from the centre exceeds the cube's circumradius (0.1 % margin) satisfies it for
+//      no face: such waves skip everything;
+//   2. let K be the candidate face reached LAST (largest dist; found by cross-multiplication, no division).
+//      A candidate i reached earlier than K by more than a sliver is still outside slab K at t = dist_i:
+//      |o_K + d_K*dist_i| = 1 + |d_K|*(dist_K - dist_i) > 1 + FUZZ, so it fails the reference's own j = K check.
+//      With a = |s - o|, b = |d| (dist = a/b), "more than a sliver" is  a_i*b_K < b_i*(a_K - mu),
+//      mu = 1e-4*(1+|o_K|) -- ~100x the rounding error of the quantities compared and of the reference's
+//      check.  Only the remaining near-ties (normally just K) get the division and the N-1 checks, in
+//      ascending order, exactly as the reference computes them.
+// Step 1 of the pruning above, on the UNNORMALISED direction v (|v|^2 = sq): the ray passes within the
+// circumradius unless |o|^2 - (o.v)^2/|v|^2 > rad2.  Conservative (0.1 % on the radius, 1e-4 on the product),
+// not bit-exact -- it only decides whether the exact predicate is evaluated at all.  Waves in which no lane
+// may hit never normalise more than dir[0], the one component the background colour needs: that saves N-1 of
+// the N IEEE divisions for ~85 % of the rays of the 6-D benchmark frames.
+// dots: |o|^2, o.right, o.up, o.forward (host); v = forward + right*sx - up*sy, so o.v follows from three of them
+__device__ __forceinline__ bool box_may_hit(int n, const float *dots, float sx, float sy, float sq) {
+    const float osq = dots[0];
+    const float ov = fmaf(-dots[2], sy, fmaf(dots[1], sx, dots[3]));
+    const float rad2 = (float)n * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
+#ifdef NT_EXP_SKIP_SLABS
+    return false;
+#else
+    return !((osq - rad2) * sq > ov * ov * 1.0001f);         // NaN -> maybe
+#endif
+}
+
+__device__ __forceinline__ void box_background(float in, float &r, float &g, float &b) {
+    // miss: i = dir[0]; i > 0 ? (i,i,i) : (0,-i,-i)   (tracer.hpp:109-113)
+    if (in > 0.0f) { r = in; g = in; b = in; }
+    else { r = 0.0f; g = -in; b = -in; }
+}
+
+template <int N>
+__device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir)[N], bool maybe, float &r, float &g, float &b) {
+    bool done = false;     // a face passed the slab test (hit, or dist >= cutoff)
+    float shade = 0.0f;
+
+    {
+        float num[N];
+        bool pre[N];
+        // candidates: dist > 0 needs a non-zero numerator with the sign of d_i; track the last-reached one
+        float aK = 0.0f, bK = 1.0f, oK = 0.0f;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float di = dir[i];
+            const float s = di < 0.0f ? 1.0f : -1.0f;
+            num[i] = s - o[i];
+            pre[i] = maybe && ((num[i] > 0.0f && di > 0.0f) || (num[i] < 0.0f && di < 0.0f));
+            const float a = fabsf(num[i]), bb = fabsf(di);
+            // a/bb > aK/bK  <=>  a*bK > aK*bb   (all positive)
+            if (pre[i] && (!any || a * bK > aK * bb)) { aK = a; bK = bb; oK = o[i]; any = true; }
+        }
+        const float mu = 1e-4f * (1.0f + fabsf(oK));
+        const float aKm = (aK - mu) * (1.0f - 1e-6f);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            // near-tie with the last-reached face (always true for that face itself); NaN-safe: !(x < y)
+            const bool tie = pre[i] && !done && !(fabsf(num[i]) * bK < fabsf(dir[i]) * aKm);
+            if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {
+                const float di = dir[i];
+                const float dist = num[i] / di;
+                bool ok = tie && dist > 0.0f;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    if (j != i) {
+                        const float p = dir[j] * dist + o[j];
+                        ok = ok && !(fabsf(p) > (1.0f + NT_FUZZ));
+                    }
+                }
+                if (ok) {
+                    done = true;
+                    // `if(dist >= cutoff) return 0` with cutoff = FLT_MAX (tracer.hpp:142): a miss
+                    if (dist >= FLT_MAX) shade = -1.0f;
+                    else {
+                        const float sine = di * (di < 0.0f ? 1.0f : -1.0f);   // dot(dir, s*e_i)
+                        shade = sine <= 0.0f ? -sine : 0.0f;
+                    }
+                }
+            }
+        }
+    }
+    if (done && shade >= 0.0f) {
+        r = shade * 1.0f;
+        g = shade * 0.5f;
+        b = shade * 0.5f;
+    } else {
+        box_background(dir[0], r, g, b);
+    }
+}
+
+// m of box_classify / box_resolve / box_cull_kernel, per unit of 1 + max|o_j|.  What it has to dominate:
+// ROUNDING_FUZZ (1.2e-6), the reference's own rounding in p_j (<= (5|o_j| + 6)*2^-24) and the v_rcp_f32 arithmetic
+// here (~2^-22*(1 + |o_j|)): under 2e-6*(1 + max|o_j|) together, 15x below this.
+#ifndef NT_BOX_MARGIN
+#define NT_BOX_MARGIN 3e-5f
+#endif
+// Which rays need the exact evaluation at all?  Everything below works on the UNNORMALISED direction v
+// (p_j(tau) = o_j + v_j*tau; the reference's dist is tau*|v|), with reciprocals from v_rcp_f32, and sorts a lane
+// that may hit into one of three classes.  m = NT_BOX_MARGIN*(1 + max|o_j|) dominates the sum of ROUNDING_FUZZ and
+// every rounding error involved (see NT_BOX_MARGIN).
+//   miss      the ray (tau > 0) stays outside the cube grown to 1+m.  Every point the reference accepts has
+//             |p_i| = 1, |p_j| <= 1+FUZZ at a dist > 0, so the reference finds no face either.
+//   hit at K  K = the entry face reached last, at tau_K; tau_K is clearly positive; at tau_K every other
+//             coordinate is inside 1-m/2 (the reference's test for K passes); and every other entry plane is
+//             crossed while p_K is still outside 1+m ((tau_K - tau_i)*|v_K| > m), so no face before K in the
+//             reference's ascending order can pass its j = K check.  The reference returns face K: shade |d_K|.
+//   unclear   anything else (edges, grazing rays, origins on or inside the cube, NaN): the wave takes the exact,
+//             reference-ordered evaluation in box_color.
+// x = the component the colour is made of: v_K for a hit, v_0 for the background.
+template <int N>
+__device__ __forceinline__ void box_classify(const float (&o)[N], const float (&v)[N], float m, bool maybe, bool &hit, bool &unclear,
+                                             float &x, float (&near)[N], float &tn, float &vK) {
+    float tn2 = -INFINITY;                                 // tn, tn2: last and second-to-last entry, unit cube
+    tn = -INFINITY;
+    vK = 0.0f;
+    float tnp = -INFINITY, tfp = INFINITY;                 // last entry / first exit, cube grown by m
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float inv = __builtin_amdgcn_rcpf(v[j]);
+        const float a = (-1.0f - o[j]) * inv, b = (1.0f - o[j]) * inv;
+        const float nr = fminf(a, b), fr = fmaxf(a, b);     // a NaN (v_j = 0 and o_j = -+1, or 0*inf) drops out
+        near[j] = nr;
+        const float w = m * fabsf(inv);
+        tnp = fmaxf(tnp, nr - w);
+        tfp = fminf(tfp, fr + w);
+        const bool later = nr > tn;
+        tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);
+        vK = later ? v[j] : vK;
+        tn = fmaxf(tn, nr);
+    }
+    const bool miss = tnp > tfp || tfp < 0.0f;
+    const float c = 1.0f - m;
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) sum = sum + fmaxf(fabsf(fmaf(v[j], tn, o[j])), c);
+    // face K itself contributes 1 - c = m; the others nothing unless they are within m of their planes
+    const bool inside = sum - (float)N * c <= 1.5f * m;
+    const bool sole = (tn - tn2) * fabsf(vK) > m;
+    const bool front = tn > 1e-3f && tn < 1e30f;
+    hit = maybe && !miss && inside && sole && front;
+    unclear = maybe && !miss && !hit;
+#ifdef NT_EXP_NOUNCLEAR
+    unclear = false;
+#endif
+    x = hit ? vK : v[0];
+}
+
+// The part of box_classify that box_resolve needs: entry times into the unit cube, the last of them, its axis.
+template <int N>
+__device__ __forceinline__ void box_entries(const float (&o)[N], const float (&v)[N], float (&near)[N], float &tn, float &vK) {
+    tn = -INFINITY;
+    vK = 0.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float inv = __builtin_amdgcn_rcpf(v[j]);
+        const float nr = fminf((-1.0f - o[j]) * inv, (1.0f - o[j]) * inv);
+        near[j] = nr;
+        vK = nr > tn ? v[j] : vK;
+        tn = fmaxf(tn, nr);
+    }
+}
+
+// The unclear lanes of a wave, resolved with the reference's own arithmetic -- but only the part of it that can
+// matter.  With near[], tn, vK from box_classify (approximate; the margins absorb that):
+//   T = { i : (tn - near_i)*|v_K| <= m }   the faces that can still be the reference's answer: any other face is
+//       entered while p_K is outside 1+m and fails its j = K check (box_classify);
+//   C = { j : |p_j(tn)| + |v_j|*m/|v_K| > 1 - m/2 }   the coordinates whose test some face of T could fail: every
+//       face of T is entered within m/|v_K| of tn, so a coordinate outside C is inside 1-m/2 at all of them.
+//       T is a subset of C (p_i(tn) is within |v_i|*m/|v_K| of +-1 for i in T).
+// The faces of T are tried in ascending order exactly as hypercube_intersects does (tracer.hpp:126-152): dist from the
+// IEEE quotient, then d_j*dist + o_j against 1+FUZZ for the j in C; d_j = v_j/len is computed for the axes of C only.
+// A lane whose tn is not a usable number gets T = C = everything, i.e. the reference's full loop.
+template <int N>
+__device__ __forceinline__ void box_resolve(const float (&o)[N], const float (&v)[N], float len, float m, const float (&near)[N], float tn,
+                                            float vK, bool unclear, bool &hit, float &x) {
+    const float aK = fabsf(vK);
+    const float slack = m * __builtin_amdgcn_rcpf(aK), lim = 1.0f - 0.5f * m;
+    bool inT[N], inC[N];
+    float d[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const bool early = (tn - near[j]) * aK > m;                                     // false for a NaN
+        const bool robust = fmaf(fabsf(v[j]), slack, fabsf(fmaf(v[j], tn, o[j]))) <= lim;  // false for a NaN
+        inT[j] = unclear && !early;
+        inC[j] = unclear && !(robust && early);
+        d[j] = 0.0f;
+        if (__builtin_amdgcn_ballot_w64(inC[j]) != 0ull) d[j] = v[j] / len;
+    }
+    bool done = false, found = false;
+    float xs = v[0];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const bool cand = inT[i] && !done;
+        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
+            const float di = d[i];
+            const float dist = ((di < 0.0f ? 1.0f : -1.0f) - o[i]) / di;
+            bool ok = cand && di != 0.0f && dist > 0.0f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (j != i) {
+                    const float p = d[j] * dist + o[j];
+                    ok = ok && !(inC[j] && fabsf(p) > (1.0f + NT_FUZZ));
+                }
+            }
+            if (ok) {
+                done = true;
+                // `if(dist >= cutoff) return 0` with cutoff = FLT_MAX (tracer.hpp:142): a miss
+                if (!(dist >= FLT_MAX)) { found = true; xs = v[i]; }
+            }
+        }
+    }
+    if (unclear) {
+        hit = found;
+        x = xs;
+    }
+}
+
+// One pixel of BoxScene from the unnormalised direction `dir` (|dir|^2 = sq), sx / sy as in the ray source.
+// PLAIN: the format is known to be plain_rgb with at most 10 bits per channel (the launcher checks).
+// DEFER: a wave with an unclear lane writes nothing and returns false (the caller hands the stretch to box_redo_kernel),
+// which keeps the resolving code -- and its registers -- out of the kernel every other wave runs.
+// REDO (box_redo_kernel): no sorting into clear and unclear -- box_resolve is complete by itself (a clear hit is T = C =
+// {K}; a clear miss fails at a coordinate of C), and in a stretch that is here because of its unclear lanes the
+// sorting of the others saves nothing.
+template <int N, bool PLAIN, bool DEFER = false, bool REDO = false>
+__device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
+                                          const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true) {
+    // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
+    const bool maybe = REDO || (rowhit && box_may_hit(N, dots, sx, sy, sq));
+    float r, g, b;
+    bool hit = false, unclear = false;
+    float x = dir[0];
+#ifndef NT_EXP_NOCLASSIFY
+    float near[N], tn = 0.0f, vK = 0.0f;
+    if (REDO) {
+        box_entries<N>(org, dir, near, tn, vK);
+        unclear = true;
+    } else if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+        box_classify<N>(org, dir, margin, maybe, hit, unclear, x, near, tn, vK);
+    }
+    // unclear lanes: the reference's arithmetic on the faces and coordinates still in question; a lane without a
+    // usable entry time (origin on or inside the cube, NaN) keeps the whole wave on box_color's full evaluation
+    if (DEFER) {
+        if (__builtin_amdgcn_ballot_w64(unclear) != 0ull) return false;
+    } else {
+        const bool hard = unclear && !(tn > 1e-3f && tn < 1e30f);
+        if (__builtin_amdgcn_ballot_w64(unclear) != 0ull && __builtin_amdgcn_ballot_w64(hard) == 0ull) {
+            box_resolve<N>(org, dir, sqrtf(sq), margin, near, tn, vK, unclear, hit, x);
+            unclear = false;
+        }
+    }
+#else
+    unclear = maybe;
+#endif
+    if (__builtin_amdgcn_ballot_w64(unclear) == 0ull) {
+        // every lane's colour is |x|/len times (1,.5,.5) (hit) or (1,1,1) / (0,1,1) (background, by the sign of x)
+        if (PLAIN || (plain_rgb(tg) && tg.plain_bits <= 10u)) {
+            // Only round(value * maxval) is stored.  |x| * rsq(sq) is within 3*2^-23 of the reference's twice-rounded
+            // |x/len| (v_rsq_f32: 1 ulp; two multiplications here; sqrt and division there), so whenever
+            // t = that * maxval keeps 2^-20*(1+t) clear of every k + 1/2 the two round to the same integer: no
+            // sqrt, no division.  (A hit also stores round(t/2).)  A wave with a lane inside a guard band (a few
+            // per cent of them at 8 bits), or with a NaN / infinity, takes the exact division below.
+            const float maxv = (float)tg.plain_maxval;
+            const float t = (fabsf(x) * __builtin_amdgcn_rsqf(sq)) * maxv;
+            const float tgb = hit ? t * 0.5f : t;
+            const bool clear_gb = fabsf(__builtin_amdgcn_fractf(tgb) - 0.5f) > fmaf(tgb, 0x1p-20f, 0x1p-20f);
+            const bool clear_r = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-20f, 0x1p-20f);
+            if (__builtin_amdgcn_ballot_w64(!(clear_gb && (clear_r || !hit))) == 0ull) {
+                uint32_t qgb = (uint32_t)(tgb + 0.5f), qr = (uint32_t)(t + 0.5f);
+                qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;    // the value may round to just above 1: clamped
+                qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
+                emit_plain(tg, pr, (hit || x > 0.0f) ? qr : 0u, qgb);
+                return true;
+            }
+        }
+        const float in = x / sqrtf(sq);
+        if (hit) {
+            // sine = d_K * (-sign d_K) <= 0, shade = -sine (tracer.hpp:105-107)
+            const float shade = fabsf(in);
+            r = shade * 1.0f;
+            g = shade * 0.5f;
+            b = shade * 0.5f;
+        } else {
+            box_background(in, r, g, b);
+        }
+    } else if (!DEFER) {
+        const float len = sqrtf(sq);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dir[j] = dir[j] / len;
+        box_color<N>(org, dir, maybe, r, g, b);
+    } else {
+        return false;
+    }
+    if (PLAIN || plain_rgb(tg)) {
+        emit_plain(tg, pr, plain_quantize(tg, r), plain_quantize(tg, g));       // g == b
+        return true;
+    }
+    emit_pixel(tg, pr, r, g, b);
+    return true;
+}
+
+// A lane renders ROWS pixels of one image column (a block: 64 columns x 4*ROWS rows; a wave still writes 64 consecutive
+// pixels of a row at a time): forward + right*sx and the wave's set-up are shared by all of them.  ROWS = BoxRows<N>
+// (8), or 16 for the packed-RGB kernel in large launches; probe mode (listed pixels) is one pixel per lane.
+#ifndef NT_BOXROWS
+#define NT_BOXROWS 8
+#endif
+template <int N> struct BoxRows { static constexpr int value = N <= 10 ? NT_BOXROWS : 1; };
+template <int N, bool PLAIN, int ROWS = BoxRows<N>::value>
+__global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg) {
+    const int tid = (int)threadIdx.x;
+    float org[N], right[N], up[N], fwd[N], dir[N];
+    load_camera<N>(cam, org, right, up, fwd);
+    float margin = fabsf(org[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
+    margin = NT_BOX_MARGIN * (1.0f + margin);
+    float dots[4];
+    if (cam.buf) {
+        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
+    } else {
+        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
+    }
+    if ((!PLAIN && tg.colors_out) || ROWS == 1) {
+        // one pixel per lane: probe mode (listed pixels)
+        const PixelRef pr = locate_pixel<64, 4>(tg, tid & 63, tid >> 6, tid);
+        if (!pr.valid) return;
+        // flat_origin_ray_source::operator() (tracer.hpp:71-75), as primary_dir, with the normalisation split off
+        const float sx = tg.fovI * ((float)pr.x - tg.half_w);
+        const float sy = tg.fovI * ((float)pr.y - tg.half_h);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dir[j] = (fwd[j] + right[j] * sx) - up[j] * sy;
+        float sq = dir[0] * dir[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+        box_pixel<N, PLAIN>(tg, pr, org, dir, sq, dots, sx, sy, margin);
+        return;
+    }
+    // the wave's number as a scalar: everything that depends on the row alone stays on the scalar unit
+    constexpr int R = ROWS;
+    const int row0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * R;
+    if (PLAIN) {
+        // ---- packed RGB, at most 10 bits a channel: the lean loop ----
+        if (row0 >= tg.row_count) return;             // (also keeps the row-code reads below inside the table's padding)
+        // Row bookkeeping is done once, one row per lane (lane l <-> row row0 + l), and read back with v_readlane:
+        // sy, up[0]*sy, the row's byte offset, whether the row exists.  Every lane stays active for that -- lanes past
+        // the right edge redo the last pixel (the same dword, the same value) instead of leaving.
+        const int lane = tid & 63;
+        const int lorow = tg.row_begin + row0 + lane;
+        int ly = lorow;
+        if (tg.band_world > 1) {
+            const int band = lorow / tg.band_rows;
+            ly = (band * tg.band_world + tg.band_rank) * tg.band_rows + (lorow - band * tg.band_rows);
+        }
+        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < R && row0 + lane < tg.row_count && ly < tg.height);
+        const float v_sy = tg.fovI * ((float)ly - tg.half_h);
+        const float v_us0 = up[0] * v_sy;
+        const long long v_off = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? lorow : ly) * tg.pitch;
+        const int v_off_lo = (int)v_off, v_off_hi = (int)(v_off >> 32);
+        int x = (int)blockIdx.x * 64 + lane;
+        x = x < tg.width ? x : tg.width - 1;
+        const long long xoff = (long long)x * tg.bpp;
+        const float sx = tg.fovI * ((float)x - tg.half_w);
+        float base[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
+        // what box_cull_kernel found out about the wave's rows, four bits a row (row rr in bits 4rr..4rr+3)
+        static_assert(R <= 16, "sixteen row codes to a qword");
+        unsigned long long rowcodes = 0ull;
+        // (rows past the last one read on into the table's padding: `valid` masks them out)
+        const uint32_t *cp = tg.cull + ((size_t)blockIdx.z * tg.row_count + row0) * tg.cull_words + (blockIdx.x >> 3);
+        const int nibble = 4 * (blockIdx.x & 7);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+            rowcodes |= (unsigned long long)((cp[rr * tg.cull_words] >> nibble) & 15u) << (4 * rr);
+        // Background rows need |dir|^2 only to ~2^-19 (see the guard below): as a quadratic in sy,
+        //   |base - up*sy|^2 = base.base - 2*sy*(base.up) + sy^2*(up.up),
+        // it costs two fma per row instead of the N-1 other components and their squares.  Its absolute error is
+        // ~2.7n*2^-24*(base.base + sy^2 up.up), and that is relative to the result as long as the cross term cannot
+        // cancel the squares: lanes check (base.up)^2 <= base.base*up.up/16 (any sane camera: up is orthogonal to
+        // forward and right), and a wave with a lane that fails it never takes the shortcut.
+        float bb = 0.0f, bu = 0.0f, uu = 0.0f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            bb = fmaf(base[j], base[j], bb);
+            bu = fmaf(base[j], up[j], bu);
+            uu = fmaf(up[j], up[j], uu);
+        }
+        const float m2bu = -2.0f * bu;
+        const bool fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
+        const float maxv = (float)tg.plain_maxval;
+        // rows painted as background outright / rows that are one face throughout / rows for the full treatment, as
+        // masks with one bit per row AT THE ROW'S NIBBLE (bit 4rr): derived from the codes with a dozen scalar
+        // operations on the whole qword
+        const unsigned long long nib = 0x1111111111111111ull;
+        unsigned long long validn = valid & 0xffffu;                       // bit rr -> bit 4rr
+        validn = (validn | (validn << 24)) & 0x000000ff000000ffull;
+        validn = (validn | (validn << 12)) & 0x000f000f000f000full;
+        validn = (validn | (validn << 6)) & 0x0303030303030303ull;
+        validn = (validn | (validn << 3)) & nib;
+        unsigned long long quick = 0ull, inner = 0ull, todo = validn;
+        // up[K]*sy of the lane's row, K = its face if it is of the second kind
+        float v_usK = 0.0f;
+        if (fastsq) {
+            const unsigned long long n = rowcodes;
+            const unsigned long long nz = (n | (n >> 1) | (n >> 2) | (n >> 3)) & nib;            // code != 0
+            const unsigned long long hi3 = ((n >> 1) & (n >> 2) & (n >> 3)) & nib;               // code is 14 or 15
+            const unsigned long long full = hi3 & n, skip = hi3 & ~n;                            // 15 / 14 (box_redo_kernel's from the start)
+            quick = validn & ~nz;
+            todo = validn & full;
+            inner = validn & nz & ~hi3;
+            (void)skip;
+            const uint32_t lk = ((uint32_t)(rowcodes >> (4 * (lane & 15))) & 15u) - 1u;
+            float upK = up[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) upK = lk == (uint32_t)j ? up[j] : upK;
+            v_usK = upK * v_sy;
+        }
+        while (quick != 0ull) {
+            const int rr = __builtin_ctzll(quick) >> 2;
+            quick &= quick - 1ull;
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+            const float us0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_us0), rr));
+            const float d0 = base[0] - us0;                           // dir[0], bit for bit
+            const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
+            // round(|dir[0]|/len * maxval), as in box_pixel, with the guard widened for sqa: sqa is within
+            // (3.7n+4)*2^-24 of the reference's sum, so t is within ~22*2^-24 < 2^-19.4 of its value (n <= 8); guard 2^-18
+            const float t = (fabsf(d0) * __builtin_amdgcn_rsqf(sqa)) * maxv;
+            const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);
+            if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
+                todo |= 1ull << (4 * rr);                                     // a lane too close to a rounding boundary
+                continue;
+            }
+            uint32_t q = (uint32_t)(t + 0.5f);
+            q = q < tg.plain_maxval ? q : tg.plain_maxval;
+            PixelRef pr;
+            pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+            emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
+        }
+        while (inner != 0ull) {
+            // every ray of the row's stretch hits face K (box_cull_kernel): the colour is |dir[K]|/len * (1, .5, .5)
+            const int rr = __builtin_ctzll(inner) >> 2;
+            inner &= inner - 1ull;
+            const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+            const float usK = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_usK), rr));
+            float bK = base[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) bK = K == (uint32_t)j ? base[j] : bK;
+            const float dK = bK - usK;                                // dir[K], bit for bit
+            const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
+            const float t = (fabsf(dK) * __builtin_amdgcn_rsqf(sqa)) * maxv, th = t * 0.5f;
+            const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f) &&
+                               fabsf(__builtin_amdgcn_fractf(th) - 0.5f) > fmaf(th, 0x1p-18f, 0x1p-18f);
+            if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
+                todo |= 1ull << (4 * rr);
+                continue;
+            }
+            uint32_t qr = (uint32_t)(t + 0.5f), qgb = (uint32_t)(th + 0.5f);
+            qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
+            qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;
+            PixelRef pr;
+            pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+            emit_plain(tg, pr, qr, qgb);
+        }
+        while (todo != 0ull) {
+            const int rr = __builtin_ctzll(todo) >> 2;
+            todo &= todo - 1ull;
+            const bool rowhit = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) != 0u;
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+            PixelRef pr;
+            pr.x = x;
+            pr.y = 0;
+            pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+            pr.hit_index = 0;
+            pr.valid = true;
+#pragma unroll
+            for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+            float sq = dir[0] * dir[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+            if (!box_pixel<N, true, true>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit)) {
+                // a lane needs the reference's face-by-face arithmetic: leave the stretch to box_redo_kernel
+                if (lane == 0)
+                    atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5),
+                             1u << (blockIdx.x & 31));
+            }
+        }
+        return;
+    }
+    // ---- any other format ----
+    const int x = (int)blockIdx.x * 64 + (tid & 63);
+    if (x >= tg.width) return;
+    const float sx = tg.fovI * ((float)x - tg.half_w);
+    float base[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
+    // the stretch codes of the wave's rows, fetched together ahead of the loop (only "culled or not" is used here)
+    uint32_t live = ~0u;
+    if (tg.cull) {
+        if (row0 >= tg.row_count) return;               // (keeps the reads inside the table's padding)
+        const uint32_t *cp = tg.cull + ((size_t)blockIdx.z * tg.row_count + row0) * tg.cull_words + (blockIdx.x >> 3);
+        live = 0u;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) live |= (((cp[rr * tg.cull_words] >> (4 * (blockIdx.x & 7))) & 15u) != 0u ? 1u : 0u) << rr;
+    }
+    for (int rr = 0; rr < R; ++rr) {
+        const int row = row0 + rr;                      // relative to row_begin; the same for the whole wave
+        if (row >= tg.row_count) return;
+        const bool rowhit = (live >> rr) & 1u;
+        const int orow = tg.row_begin + row;
+        int y = orow;
+        if (tg.band_world > 1) {
+            const int band = orow / tg.band_rows;
+            y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+        }
+        if (y >= tg.height) continue;
+        PixelRef pr;
+        pr.x = x;
+        pr.y = y;
+        pr.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+        pr.hit_index = 0;
+        pr.valid = true;
+        const float sy = tg.fovI * ((float)y - tg.half_h);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+        float sq = dir[0] * dir[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+        box_pixel<N, false>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit);
+    }
+}
+
+// The stretches box_kernel<N, true> left behind (tg.redo): one wave per (frame, row, word of 32 stretches), every set
+// bit rendered with the complete box_pixel -- classification, box_resolve, box_color.
+template <int N>
+__global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarget tg) {
+    const int tid = (int)threadIdx.x;
+    const int row = (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (row >= tg.row_count) return;
+    uint32_t todo = tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + blockIdx.x];
+    if (todo == 0u) return;
+    float org[N], right[N], up[N], fwd[N], dir[N];
+    load_camera<N>(cam, org, right, up, fwd);
+    float margin = fabsf(org[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
+    margin = NT_BOX_MARGIN * (1.0f + margin);
+    float dots[4];
+    if (cam.buf) {
+        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
+    } else {
+        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
+    }
+    const int orow = tg.row_begin + row;
+    int y = orow;
+    if (tg.band_world > 1) {
+        const int band = orow / tg.band_rows;
+        y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+    }
+    if (y >= tg.height) return;
+    const float sy = tg.fovI * ((float)y - tg.half_h);
+    while (todo != 0u) {
+        const int bit = __builtin_ctz(todo);
+        todo &= todo - 1u;
+        int x = ((int)blockIdx.x * 32 + bit) * 64 + (tid & 63);
+        x = x < tg.width ? x : tg.width - 1;            // as in box_kernel<N, true>
+        PixelRef pr;
+        pr.x = x;
+        pr.y = y;
+        pr.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+        pr.hit_index = 0;
+        pr.valid = true;
+        const float sx = tg.fovI * ((float)x - tg.half_w);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dir[j] = (fwd[j] + right[j] * sx) - up[j] * sy;
+        float sq = dir[0] * dir[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+        box_pixel<N, true, false, true>(tg, pr, org, dir, sq, dots, sx, sy, margin);
+    }
+}
+
+// What can be said about a whole 64-pixel stretch of a row?  One thread per stretch.  Its rays are v = vc + right*e
+// with vc the direction through its middle and |e| <= 32*fovI: v_j lies in [vc_j - g_j, vc_j + g_j],
+// g_j = 32*fovI*|right_j| (+1e-6 for the rounding of v itself).
+//  * code 0 -- no ray can reach the cube.  A ray that comes within h = 1 + 2m + 1e-3 of the cube in every coordinate
+//    at some tau > 0 (every ray the reference could call a hit does, see box_classify) satisfies
+//        (vc_j + g_j)*tau >= -h - o_j     and     (vc_j - g_j)*tau <= h - o_j         for every j:
+//    2n half-lines in tau; an empty intersection clears the stretch, and box_kernel paints background there without
+//    looking further.  Convexity makes this sharp: what is left is within half a stretch of the cube's silhouette.
+//  * code K+1 -- every ray clearly hits face K, K = the face the middle ray enters last.  With v_K of one sign over
+//    the stretch, tau_K = (s_K - o_K)/v_K ranges over [tlo, thi]; if for every other j the extremes of
+//    o_j + v_j*tau over that box stay inside 1 - m*(1 + |v_j|max/|v_K|min) (less 1e-4 for the arithmetic here), then for
+//    each ray the reference's test of face K passes with room to spare, and every other slab was entered at least
+//    m/|v_K| earlier, i.e. while p_K was outside 1+m, so no face before K can pass its j = K check (the argument of
+//    box_classify).  box_kernel shades such rows from v_K alone.
+//  * code 15 -- anything else: box_kernel classifies the rays one by one;  code 14 -- box_kernel skips the stretch and
+//    box_redo_kernel renders it (its redo bit is set here).
+// Reciprocals are approximate (v_rcp_f32); the slacks above are ~1000x their error.
+template <int N>
+__global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarget tg, uint32_t *out, int ncols) {
+    float org[N], right[N], up[N], fwd[N];
+    load_camera<N>(cam, org, right, up, fwd);
+    // a half-wave = 32 stretches of one row: blockIdx.x = which 32, blockIdx.y = which 8 rows
+    const int word = (int)blockIdx.x, row = (int)blockIdx.y * 8 + (int)(threadIdx.x >> 5);
+    const int col = word * 32 + (int)(threadIdx.x & 31);
+    uint32_t code = 0u;
+    if (row < tg.row_count && col < ncols) {
+        const int orow = tg.row_begin + row;
+        int y = orow;
+        if (tg.band_world > 1) {
+            const int band = orow / tg.band_rows;
+            y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+        }
+        float omax = fabsf(org[0]);
+#pragma unroll
+        for (int j = 1; j < N; ++j) omax = fmaxf(omax, fabsf(org[j]));
+        const float m = NT_BOX_MARGIN * (1.0f + omax);
+        const float h = 1.0f + 2.0f * m + 1e-3f;
+        const float sxc = tg.fovI * (((float)(col * 64) + 31.5f) - tg.half_w);
+        const float sy = tg.fovI * ((float)y - tg.half_h);
+        const float spread = 32.0f * tg.fovI;
+        float tlo = 0.0f, thi = INFINITY;
+        bool dead = false;
+        float vc[N], g[N];
+        float tn = -INFINITY, tn2 = -INFINITY, vK = 0.0f, gK = 0.0f, oK = 0.0f;
+        int K = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            vc[j] = (fwd[j] + right[j] * sxc) - up[j] * sy;
+            g[j] = fmaf(spread, fabsf(right[j]), 1e-6f);
+            const float pa = vc[j] + g[j], qa = -h - org[j];
+            const float pb = vc[j] - g[j], qb = h - org[j];
+            const float ra = qa * __builtin_amdgcn_rcpf(pa), rb = qb * __builtin_amdgcn_rcpf(pb);
+            // pa*tau >= qa bounds tau from below when pa > 0, from above when pa < 0; pb*tau <= qb the other way round
+            // (a NaN -- 0*inf -- drops out of fmaxf / fminf)
+            const float lo_a = pa > 0.0f ? ra : -INFINITY, hi_a = pa < 0.0f ? ra : INFINITY;
+            const float hi_b = pb > 0.0f ? rb : INFINITY, lo_b = pb < 0.0f ? rb : -INFINITY;
+            tlo = fmaxf(tlo, fmaxf(lo_a, lo_b));
+            thi = fminf(thi, fminf(hi_a, hi_b));
+            dead = dead || (pa == 0.0f && qa > 0.0f) || (pb == 0.0f && qb < 0.0f);
+            // the middle ray's entry into slab j (any K is verified below, so accuracy only matters for the yield)
+            const float nr = ((vc[j] < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc[j]);
+            tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);         // second-to-last entry
+            const bool later = nr > tn;
+            vK = later ? vc[j] : vK;
+            gK = later ? g[j] : gK;
+            oK = later ? org[j] : oK;
+            K = later ? j : K;
+            tn = fmaxf(tn, nr);
+        }
+        if (!(dead || tlo > thi)) {                      // a NaN keeps the stretch
+            code = 15u;
+            const float vKa = vK - gK, vKb = vK + gK;
+            if (N <= 14 && vKa * vKb > 0.0f) {
+                const float num = (vK < 0.0f ? 1.0f : -1.0f) - oK;
+                const float t1 = num * __builtin_amdgcn_rcpf(vKa), t2 = num * __builtin_amdgcn_rcpf(vKb);
+                const float t_lo = fminf(t1, t2) * (1.0f - 1e-6f), t_hi = fmaxf(t1, t2) * (1.0f + 1e-6f);
+                const float rK = m * __builtin_amdgcn_rcpf(fminf(fabsf(vKa), fabsf(vKb))) * (1.0f + 1e-6f);
+                bool ok = t_lo > 1e-3f && t_hi < 1e30f;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float va = vc[j] - g[j], vb = vc[j] + g[j];
+                    const float pmax = org[j] + fmaxf(vb * t_lo, vb * t_hi);
+                    const float pmin = org[j] + fminf(va * t_lo, va * t_hi);
+                    const float lim = (1.0f - m - 1e-4f) - fmaxf(fabsf(va), fabsf(vb)) * rK;
+                    ok = ok && (j == K || (pmax <= lim && pmin >= -lim));
+                }
+                if (ok) code = (uint32_t)K + 1u;
+            }
+            // The middle ray enters two slabs within m/|v_K| of each other: box_classify would call the rays around it
+            // unclear and box_kernel would hand the stretch to box_redo_kernel after classifying all of it -- send it
+            // there directly (code 14; only a prediction: box_redo_kernel is right for any stretch).
+            if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) code = 14u;
+        }
+    }
+    const unsigned long long direct = __builtin_amdgcn_ballot_w64(code == 14u);      // redo bits set here
+    // eight stretches to a dword
+    uint32_t packed = code << (4 * (threadIdx.x & 7));
+    packed |= (uint32_t)__shfl_xor((int)packed, 1, 64);
+    packed |= (uint32_t)__shfl_xor((int)packed, 2, 64);
+    packed |= (uint32_t)__shfl_xor((int)packed, 4, 64);
+    if (row < tg.row_count) {
+        if ((threadIdx.x & 7) == 0) out[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (col >> 3)] = packed;
+        if ((threadIdx.x & 31) == 0)
+            tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + word] = (threadIdx.x & 32) ? (uint32_t)(direct >> 32) : (uint32_t)direct;
+    }
+}
+
+template <int N>
+int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg_in) {
+    NtCameraFixed cf;
+    cf.buf = cam.buf;
+    for (int k = 0; k < 4; ++k) cf.odots[k] = cam.odots[k];
+    cf.n = N;
+    for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];
+    NtTarget tg = tg_in;
+    dim3 grid;
+    grid_for(tg, 64, tg.colors_out ? 4 : 4 * BoxRows<N>::value, li.nframes, grid);
+    tg.cull = nullptr;
+    tg.redo = nullptr;
+    tg.cull_words = 0;
+    tg.redo_words = 0;
+    if (li.cull_buf && !tg.colors_out && BoxRows<N>::value > 1) {
+        const int ncols = (tg.width + 63) / 64;
+        tg.redo_words = (ncols + 31) / 32;
+        tg.cull_words = 4 * tg.redo_words;
+        tg.redo = li.cull_buf + ((size_t)li.nframes * tg.row_count + 16) * tg.cull_words;        // 16 rows of padding after the codes
+        hipLaunchKernelGGL(box_cull_kernel<N>, dim3((unsigned)tg.redo_words, (unsigned)((tg.row_count + 7) / 8), (unsigned)li.nframes), dim3(256), 0,
+                           (hipStream_t)li.stream, cf, tg, li.cull_buf, ncols);
+        tg.cull = li.cull_buf;
+    }
+    // the common packed-RGB formats get the kernel with the format tests compiled out; it leaves the stretches that
+    // need the reference's face-by-face arithmetic to a second, small launch (it needs the bitmaps for that)
+    if ((tg.redo || BoxRows<N>::value == 1) && tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4 &&
+        !tg.colors_out) {
+        // sixteen rows a lane once there are waves to spare (the per-wave set-up is a fifth of the work at eight)
+        const long long waves8 = (long long)grid.x * grid.y * grid.z * 4;
+        if (BoxRows<N>::value > 1 && BoxRows<N>::value < 16 && waves8 >= 64 * 1024) {
+            grid_for(tg, 64, 4 * 16, li.nframes, grid);
+            hipLaunchKernelGGL((box_kernel<N, true, (BoxRows<N>::value > 1 ? 16 : 1)>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+        } else {
+            hipLaunchKernelGGL((box_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+        }
+        if (BoxRows<N>::value > 1)
+            hipLaunchKernelGGL(box_redo_kernel<N>, dim3((unsigned)tg.redo_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes),
+                               dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+    } else {
+        hipLaunchKernelGGL((box_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
+    }
+    return 0;
+}
+
+}  // namespace

@@ -1,5 +1,5 @@
 // nt_device.hpp -- structures shared by the host API (nt_api.cpp) and the HIP kernels
-// (nt_kernels.hip).  gfx950 only.
+// (nt_box.hpp, nt_composite.hpp, nt_var.hip).  gfx950 only.
 #pragma once
 #include <stdint.h>
 
@@ -122,7 +122,7 @@ struct NtCompositeDev {
     unsigned long long *stats;  // nullptr or 8 counters (nt_stats order)
 };
 
-// ---- launchers implemented in nt_kernels.hip ----
+// ---- launchers implemented in nt_var.hip (dispatch) over nt_inst_box.hip / nt_inst_composite.hip ----
 struct NtLaunchInfo {
     int n;                    // dimension
     int nframes;

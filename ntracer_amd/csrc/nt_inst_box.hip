@@ -1,0 +1,13 @@
+// nt_inst_box.hip -- instantiates the BoxScene kernels of nt_box.hpp.  The build compiles this file once per dimension
+// (-DNT_INST_N=3 .. 10, in parallel); without the macro every dimension is instantiated here.
+#include "nt_box.hpp"
+
+#define NT_DEFINE_BOX(N) \
+    int nt_box_fixed_##N(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg) { return launch_box_fixed<N>(li, cam, tg); }
+#define NT_DEFINE_BOX_(N) NT_DEFINE_BOX(N)
+
+#ifdef NT_INST_N
+NT_DEFINE_BOX_(NT_INST_N)
+#else
+NT_DEFINE_BOX(3) NT_DEFINE_BOX(4) NT_DEFINE_BOX(5) NT_DEFINE_BOX(6) NT_DEFINE_BOX(7) NT_DEFINE_BOX(8) NT_DEFINE_BOX(9) NT_DEFINE_BOX(10)
+#endif
