@@ -81,6 +81,12 @@ struct DeviceState {
     DevBuf hits;                         // primary-hit records between the two passes of a lit render
     DevBuf numer;                        // packet kernel: -(N.o + d) per (frame, simplex)
     DevBuf cull;                         // BoxScene: row culling bits
+    DevBuf checked;                      // reference-faithful normals: the exact `checked` bitmap, one column per resident lane
+    // camera tables travel through pinned host memory (a pageable source makes hipMemcpyAsync wait for the copy on the
+    // host, which stalls the launch pipeline of back-to-back calls): a ring of slots, each guarded by an event
+    struct Stage { void *host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool in_flight = false; };
+    Stage stage[8];
+    unsigned stage_next = 0;
     struct TileOrder { int tx = 0, ty = 0; DevBuf buf; };
     std::vector<std::unique_ptr<TileOrder>> tile_orders;   // packet kernel: tiles sorted centre-out, per tile grid
     int cu_count = 0;
@@ -274,6 +280,24 @@ int device_state(nt_scene *s, int dev, DeviceState *&out) {
     return NT_OK;
 }
 
+// a pinned slot of at least `bytes`, free to be overwritten (its previous copy has left the host)
+int stage_slot(DeviceState *ds, size_t bytes, DeviceState::Stage *&out) {
+    DeviceState::Stage &st = ds->stage[ds->stage_next++ % 8];
+    if (st.in_flight) {
+        HIP_TRY(hipEventSynchronize(st.done));
+        st.in_flight = false;
+    }
+    if (st.cap < bytes) {
+        if (st.host) { (void)hipHostFree(st.host); st.host = nullptr; st.cap = 0; }
+        const size_t want = std::max<size_t>(bytes, 4096);
+        HIP_TRY(hipHostMalloc(&st.host, want, hipHostMallocDefault));
+        st.cap = want;
+    }
+    if (!st.done) HIP_TRY(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    out = &st;
+    return NT_OK;
+}
+
 template <typename T>
 int upload(DevBuf &b, const std::vector<T> &v) {
     if (int r = b.ensure(std::max<size_t>(v.size() * sizeof(T), 16))) return r;
@@ -393,17 +417,17 @@ void fill_composite(const nt_scene *s, const DeviceState *ds, NtCompositeDev &c,
     c.has_scalar_prims = s->has_scalar;
     c.n_batches = s->n_batches;
     c.n_solids = s->n_solids;
+    c.n_triangles = s->n_triangles;
     c.stats = stats ? (unsigned long long *)ds->stats.p : nullptr;
+    c.checked = nullptr;
+    c.checked_words = 0;
+    c.checked_lanes = 0;
 }
 
 int check_renderable(const nt_scene *s) {
     if (s->composite) {
-        if (s->n > NT_MAX_FIXED_DIM) {
-            // run-time-n kernel: the feature set of the scripted configurations
-            const bool lights = !s->pl_color.empty() || !s->gl_color.empty();
-            if (s->n_solids || !s->all_opaque || s->any_reflective || lights)
-                return fail(NT_E_UNSUPPORTED, "composite scenes with more than %d dimensions support opaque, non-reflective simplices lit by the camera light only", NT_MAX_FIXED_DIM);
-        }
+        if (s->n > NT_MAX_FIXED_DIM && !s->all_opaque)
+            return fail(NT_E_UNSUPPORTED, "composite scenes with more than %d dimensions do not support transparent materials", NT_MAX_FIXED_DIM);
         if (!s->all_opaque && s->any_reflective && s->max_reflect_depth > 5)
             return fail(NT_E_UNSUPPORTED, "max_reflect_depth > 5 is not supported for scenes with transparent materials");
         if (s->nodes.size() >= (1u << 24)) return fail(NT_E_UNSUPPORTED, "k-d trees with 2^24 or more nodes are not supported");
@@ -523,6 +547,8 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     li.numer_buf = nullptr;
     li.numer_frames = 0;
     li.cull_buf = nullptr;
+    li.box_path = 1;
+    if (const char *bp = getenv("NTRACER_BOX_PATH")) li.box_path = atoi(bp);
     if (const char *kc = getenv("NTRACER_COMPOSITE_KERNEL")) li.kernel_choice = atoi(kc);
     int r;
     if (s->composite) {
@@ -536,9 +562,26 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         // they reach (its goldens show it), i.e. they break the invariant the shortcut relies on
         c.prune = (job.strict || env_strict || s->n_solids > 0) ? 0 : 1;
         if (c.root < 0) c.root = -1;
+        // Scenes with transparent materials or Solids are rendered with the reference's own handling of o_hit.normal (its
+        // first leaf loop lets every primitive test write to the current hit's normal ray, tracer.hpp:1001,1020 -- see
+        // composite_kernel_t<N, true>), which needs the reference's exact `checked` list: a bitmap column per resident
+        // lane.  NTRACER_CLEAN_NORMALS=1 selects the intended semantics instead (a hit keeps the normal of what was hit).
+        const char *ecl = getenv("NTRACER_CLEAN_NORMALS");
+        const bool faithful = s->n <= NT_MAX_FIXED_DIM && (!s->all_opaque || s->n_solids > 0) && !job.stats && !(ecl && atoi(ecl) != 0);
+        if (faithful) {
+            const long long words = ((long long)s->n_batches + s->n_triangles + s->n_solids + 31) / 32;
+            long long tiles = job.colors_out ? (job.probe_count + 255) / 256
+                                             : (long long)((tg.width + 15) / 16) * ((tg.row_count + 15) / 16) * job.nframes;
+            long long blocks = std::min<long long>(std::max<long long>(tiles, 1), 4096);
+            while (blocks > 64 && blocks * 256 * words * 4 > ((long long)256 << 20)) blocks /= 2;
+            if (int e = ds->checked.ensure((size_t)(blocks * 256 * words * 4))) return e;
+            c.checked = (uint32_t *)ds->checked.p;
+            c.checked_words = (int)words;
+            c.checked_lanes = (int)(blocks * 256);
+        }
         // image renders of opaque scenes made of batches go through the packet kernel (primary rays share the
         // camera origin): it needs the camera table in device memory (and, for the persistent variant, a counter)
-        const bool packetable = c.all_opaque != 0;
+        const bool packetable = c.all_opaque != 0 && !faithful;
         if (packetable && !job.stats && !job.colors_out && s->n <= NT_MAX_FIXED_DIM && li.kernel_choice != 2) {
             // persistent kernel: a zeroed work counter and the camera table in device memory (stream ordered)
             if (int e = ds->counter.ensure(8)) return e;
@@ -614,7 +657,9 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             const size_t words = (size_t)(((tg.width + 63) / 64 + 31) / 32);
             // stretch codes (4 words per redo word), 16 rows of padding (box_kernel reads a wave's rows without
             // clamping), redo bits
-            if (int e = ds->cull.ensure(((size_t)5 * job.nframes * tg.row_count + 64) * words * sizeof(uint32_t))) return e;
+            // ... or, for the fused kernels, one 8-byte redo word per tile of 64 x 32 pixels
+            const size_t tiles = (size_t)((tg.width + 63) / 64) * (size_t)((tg.row_count + 31) / 32) * (size_t)job.nframes;
+            if (int e = ds->cull.ensure(std::max(((size_t)5 * job.nframes * tg.row_count + 64) * words * sizeof(uint32_t), tiles * 8))) return e;
             li.cull_buf = (uint32_t *)ds->cull.p;
         }
         r = nt_launch_box(li, cam, tg);
@@ -791,10 +836,14 @@ void nt_scene_destroy(nt_scene_t *s) {
         (void)hipDeviceSynchronize();
         for (DevBuf *b : {&ds->nodes, &ds->items, &ds->batch_recs, &ds->batch_mats, &ds->tri_recs, &ds->tri_mats, &ds->solid_recs,
                           &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams, &ds->counter,
-                          &ds->probes, &ds->stats, &ds->hits, &ds->numer, &ds->cull})
+                          &ds->probes, &ds->stats, &ds->hits, &ds->numer, &ds->cull, &ds->checked})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
         for (auto &t : ds->tile_orders) t->buf.release();
+        for (auto &st : ds->stage) {
+            if (st.host) (void)hipHostFree(st.host);
+            if (st.done) (void)hipEventDestroy(st.done);
+        }
         if (ds->stream) (void)hipStreamDestroy(ds->stream);
     }
     delete s;
@@ -910,14 +959,21 @@ int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format 
     // abort is polled between slab launches (the reference polls per pixel, render.cpp:412)
     const int slab = abort_flag ? std::max(64, (b.owned_rows + 7) / 8 / 16 * 16) : b.owned_rows;
     bool aborted = false;
+    int rows_done = 0;
     for (int r0 = 0; r0 < b.owned_rows; r0 += slab) {
         if (abort_flag && *abort_flag) { aborted = true; break; }
         job.row_begin = r0;
         job.row_count = std::min(slab, b.owned_rows - r0);
         if (int r = enqueue(s, ds, job)) { (void)hipStreamSynchronize(ds->stream); return r; }
         if (abort_flag) HIP_TRY(hipStreamSynchronize(ds->stream));
+        rows_done = r0 + job.row_count;
     }
-    HIP_TRY(hipMemcpyAsync(dest, ds->framebuffer.p, need, hipMemcpyDeviceToHost, ds->stream));
+    // an aborted render leaves the rows it did not reach as the caller had them (the reference's workers simply stop,
+    // render.cpp:412): only the finished slabs come back.  (Rows of a banded, non-compact frame are not contiguous;
+    // there the whole buffer -- initialised from `dest` above -- is returned.)
+    size_t back = need;
+    if (aborted && (b.world == 1 || b.compact)) back = (size_t)f.pitch * (size_t)rows_done;
+    if (back) HIP_TRY(hipMemcpyAsync(dest, ds->framebuffer.p, back, hipMemcpyDeviceToHost, ds->stream));
     HIP_TRY(hipStreamSynchronize(ds->stream));
     if (stats) {
         unsigned long long v[8];
@@ -979,15 +1035,20 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
     const int n = s->n;
-    std::vector<float> packed((size_t)nframes * 4 * n + (size_t)nframes * 4);
+    const size_t cam_floats = (size_t)nframes * 4 * n + (size_t)nframes * 4;
+    DeviceState::Stage *st = nullptr;
+    if (int r = stage_slot(ds, cam_floats * sizeof(float), st)) return r;
+    float *packed = (float *)st->host;
     for (int fidx = 0; fidx < nframes; ++fidx) {
-        pack_camera(n, origins + (size_t)fidx * n, axes + (size_t)fidx * n * n, packed.data() + (size_t)fidx * 4 * n);
-        camera_dots(n, origins + (size_t)fidx * n, axes + (size_t)fidx * n * n, packed.data() + (size_t)nframes * 4 * n + (size_t)fidx * 4);
+        pack_camera(n, origins + (size_t)fidx * n, axes + (size_t)fidx * n * n, packed + (size_t)fidx * 4 * n);
+        camera_dots(n, origins + (size_t)fidx * n, axes + (size_t)fidx * n * n, packed + (size_t)nframes * 4 * n + (size_t)fidx * 4);
     }
     // a camera table that earlier launches may still read must not be overwritten: grow-only buffer,
     // refilled only after the stream that used it has drained (same-stream ordering)
-    if (int r = ds->cams.ensure(packed.size() * sizeof(float))) return r;
-    HIP_TRY(hipMemcpyAsync(ds->cams.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    if (int r = ds->cams.ensure(cam_floats * sizeof(float))) return r;
+    HIP_TRY(hipMemcpyAsync(ds->cams.p, packed, cam_floats * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    HIP_TRY(hipEventRecord(st->done, (hipStream_t)hip_stream));
+    st->in_flight = true;
     const bool stats = opts && opts->collect_stats;
     if (int r = prepare_stats(ds, (hipStream_t)hip_stream, stats)) return r;
     if (stats) { s->have_stats = false; s->stats_device = dev; }

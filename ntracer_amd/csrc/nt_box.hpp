@@ -230,6 +230,23 @@ __device__ __forceinline__ void box_resolve(const float (&o)[N], const float (&v
     }
 }
 
+// Three fp32 channels that are plain components (tg.plain_f32, 12-byte pixels on 4-byte-aligned rows), BoxScene colours
+// (g == b): the bytes emit_pixel writes for this layout -- clamp, big-endian floats or the reversed pixel -- as one
+// 12-byte store.
+__device__ __forceinline__ void emit_f32x3(const NtTarget &tg, long long offset, float r, float gb) {
+    r = r > 0.0f ? r : 0.0f;          // simd::clamp, as in channel_value
+    r = r < 1.0f ? r : 1.0f;
+    gb = gb > 0.0f ? gb : 0.0f;
+    gb = gb < 1.0f ? gb : 1.0f;
+    uint32_t vr = __float_as_uint(r), vgb = __float_as_uint(gb);
+    if (!tg.reversed) { vr = bswap32(vr); vgb = bswap32(vgb); }
+    uint3 w;
+    w.x = tg.plain_f32[tg.reversed ? 2 : 0] == 0 ? vr : vgb;
+    w.y = tg.plain_f32[1] == 0 ? vr : vgb;
+    w.z = tg.plain_f32[tg.reversed ? 0 : 2] == 0 ? vr : vgb;
+    *reinterpret_cast<uint3 *>(tg.dest + offset) = w;
+}
+
 // One pixel of BoxScene from the unnormalised direction `dir` (|dir|^2 = sq), sx / sy as in the ray source.
 // PLAIN: the format is known to be plain_rgb with at most 10 bits per channel (the launcher checks).
 // DEFER: a wave with an unclear lane writes nothing and returns false (the caller hands the stretch to box_redo_kernel),
@@ -237,7 +254,7 @@ __device__ __forceinline__ void box_resolve(const float (&o)[N], const float (&v
 // REDO (box_redo_kernel): no sorting into clear and unclear -- box_resolve is complete by itself (a clear hit is T = C =
 // {K}; a clear miss fails at a coordinate of C), and in a stretch that is here because of its unclear lanes the
 // sorting of the others saves nothing.
-template <int N, bool PLAIN, bool DEFER = false, bool REDO = false>
+template <int N, bool PLAIN, bool DEFER = false, bool REDO = false, bool F32 = false>
 __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
                                           const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true) {
     // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
@@ -305,6 +322,10 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
         box_color<N>(org, dir, maybe, r, g, b);
     } else {
         return false;
+    }
+    if (F32) {
+        emit_f32x3(tg, pr.offset, r, g);                                        // g == b
+        return true;
     }
     if (PLAIN || plain_rgb(tg)) {
         emit_plain(tg, pr, plain_quantize(tg, r), plain_quantize(tg, g));       // g == b
@@ -615,6 +636,75 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
 //  * code 15 -- anything else: box_kernel classifies the rays one by one;  code 14 -- box_kernel skips the stretch and
 //    box_redo_kernel renders it (its redo bit is set here).
 // Reciprocals are approximate (v_rcp_f32); the slacks above are ~1000x their error.
+// The code of one 64-pixel stretch (see the comment above): row y of the image, stretch `col` of the row.
+template <int N>
+__device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], const float (&right)[N], const float (&up)[N], const float (&fwd)[N],
+                                                     const NtTarget &tg, int y, int col) {
+    uint32_t code = 0u;
+    float omax = fabsf(org[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) omax = fmaxf(omax, fabsf(org[j]));
+    const float m = NT_BOX_MARGIN * (1.0f + omax);
+    const float h = 1.0f + 2.0f * m + 1e-3f;
+    const float sxc = tg.fovI * (((float)(col * 64) + 31.5f) - tg.half_w);
+    const float sy = tg.fovI * ((float)y - tg.half_h);
+    const float spread = 32.0f * tg.fovI;
+    float tlo = 0.0f, thi = INFINITY;
+    bool dead = false;
+    float vc[N], g[N];
+    float tn = -INFINITY, tn2 = -INFINITY, vK = 0.0f, gK = 0.0f, oK = 0.0f;
+    int K = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        vc[j] = (fwd[j] + right[j] * sxc) - up[j] * sy;
+        g[j] = fmaf(spread, fabsf(right[j]), 1e-6f);
+        const float pa = vc[j] + g[j], qa = -h - org[j];
+        const float pb = vc[j] - g[j], qb = h - org[j];
+        const float ra = qa * __builtin_amdgcn_rcpf(pa), rb = qb * __builtin_amdgcn_rcpf(pb);
+        // pa*tau >= qa bounds tau from below when pa > 0, from above when pa < 0; pb*tau <= qb the other way round
+        // (a NaN -- 0*inf -- drops out of fmaxf / fminf)
+        const float lo_a = pa > 0.0f ? ra : -INFINITY, hi_a = pa < 0.0f ? ra : INFINITY;
+        const float hi_b = pb > 0.0f ? rb : INFINITY, lo_b = pb < 0.0f ? rb : -INFINITY;
+        tlo = fmaxf(tlo, fmaxf(lo_a, lo_b));
+        thi = fminf(thi, fminf(hi_a, hi_b));
+        dead = dead || (pa == 0.0f && qa > 0.0f) || (pb == 0.0f && qb < 0.0f);
+        // the middle ray's entry into slab j (any K is verified below, so accuracy only matters for the yield)
+        const float nr = ((vc[j] < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc[j]);
+        tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);         // second-to-last entry
+        const bool later = nr > tn;
+        vK = later ? vc[j] : vK;
+        gK = later ? g[j] : gK;
+        oK = later ? org[j] : oK;
+        K = later ? j : K;
+        tn = fmaxf(tn, nr);
+    }
+    if (!(dead || tlo > thi)) {                      // a NaN keeps the stretch
+        code = 15u;
+        const float vKa = vK - gK, vKb = vK + gK;
+        if (N <= 14 && vKa * vKb > 0.0f) {
+            const float num = (vK < 0.0f ? 1.0f : -1.0f) - oK;
+            const float t1 = num * __builtin_amdgcn_rcpf(vKa), t2 = num * __builtin_amdgcn_rcpf(vKb);
+            const float t_lo = fminf(t1, t2) * (1.0f - 1e-6f), t_hi = fmaxf(t1, t2) * (1.0f + 1e-6f);
+            const float rK = m * __builtin_amdgcn_rcpf(fminf(fabsf(vKa), fabsf(vKb))) * (1.0f + 1e-6f);
+            bool ok = t_lo > 1e-3f && t_hi < 1e30f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float va = vc[j] - g[j], vb = vc[j] + g[j];
+                const float pmax = org[j] + fmaxf(vb * t_lo, vb * t_hi);
+                const float pmin = org[j] + fminf(va * t_lo, va * t_hi);
+                const float lim = (1.0f - m - 1e-4f) - fmaxf(fabsf(va), fabsf(vb)) * rK;
+                ok = ok && (j == K || (pmax <= lim && pmin >= -lim));
+            }
+            if (ok) code = (uint32_t)K + 1u;
+        }
+        // The middle ray enters two slabs within m/|v_K| of each other: box_classify would call the rays around it
+        // unclear and box_kernel would hand the stretch to box_redo_kernel after classifying all of it -- send it
+        // there directly (code 14; only a prediction: box_redo_kernel is right for any stretch).
+        if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) code = 14u;
+    }
+    return code;
+}
+
 template <int N>
 __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarget tg, uint32_t *out, int ncols) {
     float org[N], right[N], up[N], fwd[N];
@@ -630,67 +720,7 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
             const int band = orow / tg.band_rows;
             y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
         }
-        float omax = fabsf(org[0]);
-#pragma unroll
-        for (int j = 1; j < N; ++j) omax = fmaxf(omax, fabsf(org[j]));
-        const float m = NT_BOX_MARGIN * (1.0f + omax);
-        const float h = 1.0f + 2.0f * m + 1e-3f;
-        const float sxc = tg.fovI * (((float)(col * 64) + 31.5f) - tg.half_w);
-        const float sy = tg.fovI * ((float)y - tg.half_h);
-        const float spread = 32.0f * tg.fovI;
-        float tlo = 0.0f, thi = INFINITY;
-        bool dead = false;
-        float vc[N], g[N];
-        float tn = -INFINITY, tn2 = -INFINITY, vK = 0.0f, gK = 0.0f, oK = 0.0f;
-        int K = 0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            vc[j] = (fwd[j] + right[j] * sxc) - up[j] * sy;
-            g[j] = fmaf(spread, fabsf(right[j]), 1e-6f);
-            const float pa = vc[j] + g[j], qa = -h - org[j];
-            const float pb = vc[j] - g[j], qb = h - org[j];
-            const float ra = qa * __builtin_amdgcn_rcpf(pa), rb = qb * __builtin_amdgcn_rcpf(pb);
-            // pa*tau >= qa bounds tau from below when pa > 0, from above when pa < 0; pb*tau <= qb the other way round
-            // (a NaN -- 0*inf -- drops out of fmaxf / fminf)
-            const float lo_a = pa > 0.0f ? ra : -INFINITY, hi_a = pa < 0.0f ? ra : INFINITY;
-            const float hi_b = pb > 0.0f ? rb : INFINITY, lo_b = pb < 0.0f ? rb : -INFINITY;
-            tlo = fmaxf(tlo, fmaxf(lo_a, lo_b));
-            thi = fminf(thi, fminf(hi_a, hi_b));
-            dead = dead || (pa == 0.0f && qa > 0.0f) || (pb == 0.0f && qb < 0.0f);
-            // the middle ray's entry into slab j (any K is verified below, so accuracy only matters for the yield)
-            const float nr = ((vc[j] < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc[j]);
-            tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);         // second-to-last entry
-            const bool later = nr > tn;
-            vK = later ? vc[j] : vK;
-            gK = later ? g[j] : gK;
-            oK = later ? org[j] : oK;
-            K = later ? j : K;
-            tn = fmaxf(tn, nr);
-        }
-        if (!(dead || tlo > thi)) {                      // a NaN keeps the stretch
-            code = 15u;
-            const float vKa = vK - gK, vKb = vK + gK;
-            if (N <= 14 && vKa * vKb > 0.0f) {
-                const float num = (vK < 0.0f ? 1.0f : -1.0f) - oK;
-                const float t1 = num * __builtin_amdgcn_rcpf(vKa), t2 = num * __builtin_amdgcn_rcpf(vKb);
-                const float t_lo = fminf(t1, t2) * (1.0f - 1e-6f), t_hi = fmaxf(t1, t2) * (1.0f + 1e-6f);
-                const float rK = m * __builtin_amdgcn_rcpf(fminf(fabsf(vKa), fabsf(vKb))) * (1.0f + 1e-6f);
-                bool ok = t_lo > 1e-3f && t_hi < 1e30f;
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    const float va = vc[j] - g[j], vb = vc[j] + g[j];
-                    const float pmax = org[j] + fmaxf(vb * t_lo, vb * t_hi);
-                    const float pmin = org[j] + fminf(va * t_lo, va * t_hi);
-                    const float lim = (1.0f - m - 1e-4f) - fmaxf(fabsf(va), fabsf(vb)) * rK;
-                    ok = ok && (j == K || (pmax <= lim && pmin >= -lim));
-                }
-                if (ok) code = (uint32_t)K + 1u;
-            }
-            // The middle ray enters two slabs within m/|v_K| of each other: box_classify would call the rays around it
-            // unclear and box_kernel would hand the stretch to box_redo_kernel after classifying all of it -- send it
-            // there directly (code 14; only a prediction: box_redo_kernel is right for any stretch).
-            if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) code = 14u;
-        }
+        code = box_stretch_code<N>(org, right, up, fwd, tg, y, col);
     }
     const unsigned long long direct = __builtin_amdgcn_ballot_w64(code == 14u);      // redo bits set here
     // eight stretches to a dword
@@ -702,6 +732,290 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
         if ((threadIdx.x & 7) == 0) out[((size_t)blockIdx.z * tg.row_count + row) * tg.cull_words + (col >> 3)] = packed;
         if ((threadIdx.x & 31) == 0)
             tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + word] = (threadIdx.x & 32) ? (uint32_t)(direct >> 32) : (uint32_t)direct;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// The fused path for the two formats the reference's scripts render into (packed plain RGB of <= 10 bits a channel in
+// one aligned dword -- RGBX8 & co.: F32 = false; three plain fp32 channels, 12-byte pixels: F32 = true):
+//
+//   box_tile_kernel<N, F32, ROWS>       a block = 64 columns x 4*ROWS rows.  Wave 0 first works out the stretch codes of
+//                                       the tile (box_stretch_code, one row per lane) and leaves them in LDS; after the
+//                                       barrier every wave renders its ROWS rows from them with the lean loops.  Rows it
+//                                       cannot settle (code 14, or a lane that needs the reference's face-by-face
+//                                       arithmetic) are recorded in a 16-bit mask per wave: four of them make the
+//                                       tile's 64-bit redo word, [frame][tile row][tile column].
+//   box_redo_tile_kernel<N, F32, ROWS>  same grid; a block whose redo word is zero leaves at once, otherwise its four
+//                                       waves share the marked rows out among themselves (they have the column, hence
+//                                       forward + right*sx, in common) and render them with box_pixel<REDO>.
+// No pre-kernel, no atomics, no scratch besides the redo words (8 bytes per 64 x 4*ROWS pixels).
+// --------------------------------------------------------------------------------------
+template <int N, bool F32, int ROWS>
+__global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarget tg, uint16_t *redo16) {
+    static_assert(ROWS == 8 || ROWS == 16, "sixteen row codes to a qword");
+    constexpr int R = ROWS;
+    __shared__ uint32_t s_code[64];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float org[N], right[N], up[N], fwd[N], dir[N];
+    load_camera<N>(cam, org, right, up, fwd);
+    float margin = fabsf(org[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
+    margin = NT_BOX_MARGIN * (1.0f + margin);
+    float dots[4];
+    if (cam.buf) {
+        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
+    } else {
+        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
+    }
+    const int tile_row0 = (int)blockIdx.y * 4 * R;
+    // ---- phase 1: the tile's stretch codes, one row per lane of wave 0
+    if (wv == 0) {
+        uint32_t code = 0u;
+        const int trow = tile_row0 + lane;
+        if (lane < 4 * R && trow < tg.row_count) {
+            const int orow = tg.row_begin + trow;
+            int y = orow;
+            if (tg.band_world > 1) {
+                const int band = orow / tg.band_rows;
+                y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+            }
+            if (y < tg.height) code = box_stretch_code<N>(org, right, up, fwd, tg, y, (int)blockIdx.x);
+        }
+        // rows of wave w in nibbles of s_code[2w] (rows 0..7) and s_code[2w + 1] (rows 8..15)
+        uint32_t packed = code << (4 * (lane & 7));
+        packed |= (uint32_t)__shfl_xor((int)packed, 1, 64);
+        packed |= (uint32_t)__shfl_xor((int)packed, 2, 64);
+        packed |= (uint32_t)__shfl_xor((int)packed, 4, 64);
+        if ((lane & 7) == 0) {
+            const int grp = lane >> 3;                                   // eight rows each
+            const int slot = R == 16 ? grp : 2 * grp;                    // R == 8: wave w's rows are group w
+            s_code[slot] = packed;
+            if (R == 8) s_code[slot + 1] = 0u;
+        }
+    }
+    __syncthreads();
+    const int row0 = tile_row0 + wv * R;
+    uint32_t redo_bits = 0u;                              // rows (bit rr) left to box_redo_tile_kernel
+    if (row0 < tg.row_count) {
+        unsigned long long rowcodes = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[2 * wv + 1]) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[2 * wv]);
+        // Row bookkeeping once per wave, one row per lane (lane l <-> row row0 + l), read back with v_readlane; every
+        // lane stays active -- lanes past the right edge redo the last pixel (same bytes, same value) instead of leaving
+        const int lorow = tg.row_begin + row0 + lane;
+        int ly = lorow;
+        if (tg.band_world > 1) {
+            const int band = lorow / tg.band_rows;
+            ly = (band * tg.band_world + tg.band_rank) * tg.band_rows + (lorow - band * tg.band_rows);
+        }
+        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < R && row0 + lane < tg.row_count && ly < tg.height);
+        const float v_sy = tg.fovI * ((float)ly - tg.half_h);
+        const float v_us0 = up[0] * v_sy;
+        const long long v_off = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? lorow : ly) * tg.pitch;
+        const int v_off_lo = (int)v_off, v_off_hi = (int)(v_off >> 32);
+        int x = (int)blockIdx.x * 64 + lane;
+        x = x < tg.width ? x : tg.width - 1;
+        const long long xoff = (long long)x * tg.bpp;
+        const float sx = tg.fovI * ((float)x - tg.half_w);
+        float base[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
+        const unsigned long long nib = 0x1111111111111111ull;
+        unsigned long long validn = valid & 0xffffu;                       // bit rr -> bit 4rr
+        validn = (validn | (validn << 24)) & 0x000000ff000000ffull;
+        validn = (validn | (validn << 12)) & 0x000f000f000f000full;
+        validn = (validn | (validn << 6)) & 0x0303030303030303ull;
+        validn = (validn | (validn << 3)) & nib;
+        const unsigned long long nc = rowcodes;
+        const unsigned long long nz = (nc | (nc >> 1) | (nc >> 2) | (nc >> 3)) & nib;            // code != 0
+        const unsigned long long hi3 = ((nc >> 1) & (nc >> 2) & (nc >> 3)) & nib;                // code is 14 or 15
+        unsigned long long quick = validn & ~nz, todo = validn & hi3 & nc, inner = validn & nz & ~hi3;
+        {
+            unsigned long long skip = validn & hi3 & ~nc;                                        // code 14: not looked at here
+            while (skip != 0ull) {
+                redo_bits |= 1u << (__builtin_ctzll(skip) >> 2);
+                skip &= skip - 1ull;
+            }
+        }
+        // up[K]*sy of the lane's row, K = its face if the row is one face throughout
+        float v_usK;
+        {
+            const uint32_t lk = ((uint32_t)(rowcodes >> (4 * (lane & 15))) & 15u) - 1u;
+            float upK = up[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) upK = lk == (uint32_t)j ? up[j] : upK;
+            v_usK = upK * v_sy;
+        }
+        if (!F32) {
+            // ---- packed RGB: guarded rsq quantisation (see box_kernel<N, true>)
+            float bb = 0.0f, bu = 0.0f, uu = 0.0f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                bb = fmaf(base[j], base[j], bb);
+                bu = fmaf(base[j], up[j], bu);
+                uu = fmaf(up[j], up[j], uu);
+            }
+            const float m2bu = -2.0f * bu;
+            const bool fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
+            const float maxv = (float)tg.plain_maxval;
+            if (!fastsq) {
+                todo |= quick | inner;
+                quick = 0ull;
+                inner = 0ull;
+            }
+            while (quick != 0ull) {
+                const int rr = __builtin_ctzll(quick) >> 2;
+                quick &= quick - 1ull;
+                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+                const float us0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_us0), rr));
+                const float d0 = base[0] - us0;                           // dir[0], bit for bit
+                const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
+                const float t = (fabsf(d0) * __builtin_amdgcn_rsqf(sqa)) * maxv;
+                const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);
+                if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
+                    todo |= 1ull << (4 * rr);                                     // a lane too close to a rounding boundary
+                    continue;
+                }
+                uint32_t q = (uint32_t)(t + 0.5f);
+                q = q < tg.plain_maxval ? q : tg.plain_maxval;
+                PixelRef pr;
+                pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+                emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
+            }
+            while (inner != 0ull) {
+                const int rr = __builtin_ctzll(inner) >> 2;
+                inner &= inner - 1ull;
+                const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
+                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+                const float usK = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_usK), rr));
+                float bK = base[0];
+#pragma unroll
+                for (int j = 1; j < N; ++j) bK = K == (uint32_t)j ? base[j] : bK;
+                const float dK = bK - usK;                                // dir[K], bit for bit
+                const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
+                const float t = (fabsf(dK) * __builtin_amdgcn_rsqf(sqa)) * maxv, th = t * 0.5f;
+                const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f) &&
+                                   fabsf(__builtin_amdgcn_fractf(th) - 0.5f) > fmaf(th, 0x1p-18f, 0x1p-18f);
+                if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
+                    todo |= 1ull << (4 * rr);
+                    continue;
+                }
+                uint32_t qr = (uint32_t)(t + 0.5f), qgb = (uint32_t)(th + 0.5f);
+                qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
+                qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;
+                PixelRef pr;
+                pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+                emit_plain(tg, pr, qr, qgb);
+            }
+        } else {
+            // ---- fp32 channels: the stored value IS x / sqrtf(sq), so the reference's sum, square root and division are
+            // done as they stand -- but on rows whose code says which x it is, nothing else is
+            unsigned long long easy = quick | inner;
+            while (easy != 0ull) {
+                const int rr = __builtin_ctzll(easy) >> 2;
+                easy &= easy - 1ull;
+                const uint32_t code = (uint32_t)(rowcodes >> (4 * rr)) & 15u;          // 0, or K + 1
+                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+#pragma unroll
+                for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+                float sq = dir[0] * dir[0];
+#pragma unroll
+                for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+                float xk = dir[0];
+#pragma unroll
+                for (int j = 1; j < N; ++j) xk = code == (uint32_t)(j + 1) ? dir[j] : xk;
+                const float in = xk / sqrtf(sq);
+                float r, gb;
+                if (code != 0u) {
+                    const float shade = fabsf(in);          // sine = d_K * (-sign d_K) <= 0, shade = -sine (tracer.hpp:105-107)
+                    r = shade * 1.0f;
+                    gb = shade * 0.5f;
+                } else {
+                    float b_;
+                    box_background(in, r, gb, b_);
+                }
+                const long long off = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+                emit_f32x3(tg, off, r, gb);
+            }
+        }
+        while (todo != 0ull) {
+            const int rr = __builtin_ctzll(todo) >> 2;
+            todo &= todo - 1ull;
+            const bool rowhit = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) != 0u;
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+            PixelRef pr;
+            pr.x = x;
+            pr.y = 0;
+            pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+            pr.hit_index = 0;
+            pr.valid = true;
+#pragma unroll
+            for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+            float sq = dir[0] * dir[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+            if (!box_pixel<N, !F32, true, false, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit)) redo_bits |= 1u << rr;
+        }
+    }
+    // every wave of the grid writes its part of the tile's redo word: nothing to clear beforehand
+    if (lane == 0) redo16[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wv] = (uint16_t)redo_bits;
+}
+
+template <int N, bool F32, int ROWS>
+__global__ __launch_bounds__(256) void box_redo_tile_kernel(NtCameraFixed cam, NtTarget tg, const unsigned long long *redo64) {
+    constexpr int R = ROWS;
+    unsigned long long todo = redo64[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x];       // uniform: scalar load
+    if (todo == 0ull) return;
+    const int tid = (int)threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float org[N], right[N], up[N], fwd[N], dir[N];
+    load_camera<N>(cam, org, right, up, fwd);
+    float margin = fabsf(org[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
+    margin = NT_BOX_MARGIN * (1.0f + margin);
+    float dots[4];
+    if (cam.buf) {
+        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
+    } else {
+        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
+    }
+    int x = (int)blockIdx.x * 64 + (tid & 63);
+    x = x < tg.width ? x : tg.width - 1;            // as in box_tile_kernel
+    const float sx = tg.fovI * ((float)x - tg.half_w);
+    float base[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
+    // the marked rows in order, dealt round-robin to the four waves
+    int ord = 0;
+    while (todo != 0ull) {
+        const int bit = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        if ((ord++ & 3) != wv) continue;
+        const int row = (int)blockIdx.y * 4 * R + (bit >> 4) * R + (bit & 15);       // bit 16w + rr: row rr of wave w
+        const int orow = tg.row_begin + row;
+        int y = orow;
+        if (tg.band_world > 1) {
+            const int band = orow / tg.band_rows;
+            y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+        }
+        PixelRef pr;
+        pr.x = x;
+        pr.y = y;
+        pr.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+        pr.hit_index = 0;
+        pr.valid = true;
+        const float sy = tg.fovI * ((float)y - tg.half_h);
+#pragma unroll
+        for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+        float sq = dir[0] * dir[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+        box_pixel<N, !F32, false, true, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin);
     }
 }
 
@@ -719,6 +1033,37 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     tg.redo = nullptr;
     tg.cull_words = 0;
     tg.redo_words = 0;
+    // the two formats of the reference's scripts take the fused kernels (no pre-kernel): packed plain RGB of at most 10 bits
+    // a channel in one aligned dword, and three plain fp32 channels
+    const bool fmt_rgb = tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4;
+    const bool fmt_f32 = tg.plain_f32[0] >= 0 && tg.bpp == 12 && tg.aligned4;
+    if (li.cull_buf && !tg.colors_out && BoxRows<N>::value > 1 && (fmt_rgb || fmt_f32) && li.box_path != 0) {
+        hipStream_t st = (hipStream_t)li.stream;
+        // sixteen rows a lane once there are waves to spare (the per-wave set-up is a fifth of the work at eight)
+        const long long waves8 = (long long)((tg.width + 63) / 64) * ((tg.row_count + 31) / 32) * li.nframes * 4;
+        const bool r16 = waves8 >= 64 * 1024;
+        const dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + (r16 ? 63 : 31)) / (r16 ? 64 : 32)), (unsigned)li.nframes);
+        uint16_t *r16p = (uint16_t *)li.cull_buf;
+        const unsigned long long *r64p = (const unsigned long long *)li.cull_buf;
+        if (fmt_rgb) {
+            if (r16) {
+                hipLaunchKernelGGL((box_tile_kernel<N, false, 16>), tgrid, dim3(256), 0, st, cf, tg, r16p);
+                hipLaunchKernelGGL((box_redo_tile_kernel<N, false, 16>), tgrid, dim3(256), 0, st, cf, tg, r64p);
+            } else {
+                hipLaunchKernelGGL((box_tile_kernel<N, false, 8>), tgrid, dim3(256), 0, st, cf, tg, r16p);
+                hipLaunchKernelGGL((box_redo_tile_kernel<N, false, 8>), tgrid, dim3(256), 0, st, cf, tg, r64p);
+            }
+        } else {
+            if (r16) {
+                hipLaunchKernelGGL((box_tile_kernel<N, true, 16>), tgrid, dim3(256), 0, st, cf, tg, r16p);
+                hipLaunchKernelGGL((box_redo_tile_kernel<N, true, 16>), tgrid, dim3(256), 0, st, cf, tg, r64p);
+            } else {
+                hipLaunchKernelGGL((box_tile_kernel<N, true, 8>), tgrid, dim3(256), 0, st, cf, tg, r16p);
+                hipLaunchKernelGGL((box_redo_tile_kernel<N, true, 8>), tgrid, dim3(256), 0, st, cf, tg, r64p);
+            }
+        }
+        return 0;
+    }
     if (li.cull_buf && !tg.colors_out && BoxRows<N>::value > 1) {
         const int ncols = (tg.width + 63) / 64;
         tg.redo_words = (ncols + 31) / 32;

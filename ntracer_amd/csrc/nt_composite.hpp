@@ -889,20 +889,158 @@ __device__ __forceinline__ float test_item(const NtCompositeDev &sc, int item, c
     return solid_intersects<N>(sc, idx, o, d, cutoff, false, no, nd);
 }
 
+// --------------------------------------------------------------------------------------
+// Reference-faithful normals.  The reference's tests take the normal ray to fill in as an in/out argument, and the
+// first loop of kd_leaf::intersects passes o_hit.normal itself (tracer.hpp:1001,1020).  What a test writes there and
+// when, restated exactly (the oracle does the same, oracle/ntracer_oracle.c):
+//   * triangle / triangle_batch: nothing unless the test succeeds (tracer.hpp:431-437, 583-596);
+//   * hypersphere: nothing unless it succeeds (:154-173);
+//   * hypercube: normal.origin[i] = +-1 for every axis it tries and normal.origin[j] = p_j for the coordinates it checks
+//     before the first one that fails -- in the solid's LOCAL coordinates, success or not (:126-152); direction and the
+//     transformation back to world space only on success (:262-275).
+// So a later test that finds a transparent surface, or a later Solid cube that is missed, leaves its marks on the normal
+// ray of an opaque hit found earlier -- and base_color shades that hit with them.
+// --------------------------------------------------------------------------------------
+
+// hypercube_intersects (tracer.hpp:126-152) with its writes to `no` / `nd` in the reference's order
+template <int N>
+__device__ __forceinline__ float cube_local_marks(const float (&o)[N], const float (&d)[N], float cutoff, float (&no)[N], float (&nd)[N]) {
+    bool alive = true;          // the function has not returned yet
+    float result = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float di = d[i];
+        const bool tried = alive && di != 0.0f;
+        const float s = di < 0.0f ? 1.0f : -1.0f;
+        if (tried) no[i] = s;
+        const float dist = (s - o[i]) / di;
+        bool going = tried && dist > 0.0f;        // inside the j loop, no miss so far
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j != i) {
+                const float p = d[j] * dist + o[j];
+                if (going) no[j] = p;
+                going = going && !(fabsf(p) > (1.0f + NT_FUZZ));
+            }
+        }
+        if (going) {
+            alive = false;
+            if (!(dist >= cutoff)) {
+                result = dist;
+#pragma unroll
+                for (int j = 0; j < N; ++j) nd[j] = j == i ? s : 0.0f;        // (no[i] == s)
+            }
+        }
+    }
+    return result;
+}
+
+// solid::intersects (tracer.hpp:251-276) writing through to the caller's normal ray as the reference does
+template <int N>
+__device__ __noinline__ float solid_intersects_marks(const NtCompositeDev &sc, int idx, const float (&o)[N], const float (&d)[N], float cutoff,
+                                                     float (&no)[N], float (&nd)[N]) {
+    const float *orient = sc.solid_recs + (size_t)idx * (2 * N * N + N);
+    const float *inv = orient + N * N;
+    const float *pos = inv + N * N;
+    float lo[N], ld[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        lo[i] = dotP<N>(inv + i * N, o) - pos[i];
+        ld[i] = dotP<N>(inv + i * N, d);
+    }
+    float dist;
+    if (sc.solid_types[idx] == 1) {
+        dist = cube_local_marks<N>(lo, ld, cutoff, no, nd);
+    } else {
+        float so[N], sd[N];
+        dist = sphere_local<N>(lo, ld, cutoff, so, sd);
+        if (dist != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { no[i] = so[i]; nd[i] = sd[i]; }
+        }
+    }
+    if (dist == 0.0f) return 0.0f;
+    float tmp[N], ndl[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { tmp[i] = no[i] + pos[i]; ndl[i] = nd[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        no[i] = dotP<N>(orient + i * N, tmp);
+        nd[i] = dotP<N>(orient + i * N, ndl);
+    }
+    return dist;
+}
+
+// test_item that fills in (no, nd) the way the reference's tests fill in their `normal` argument
+template <int N>
+__device__ __forceinline__ float test_item_marks(const NtCompositeDev &sc, int item, const float (&o)[N], const float (&d)[N], float cutoff,
+                                                 int skip_item, int skip_lane, int &lane_out, float (&no)[N], float (&nd)[N]) {
+    if ((item & 3) == 2) {
+        lane_out = -1;
+        return solid_intersects_marks<N>(sc, item >> 2, o, d, cutoff, no, nd);
+    }
+    const float t = test_item<N>(sc, item, o, d, cutoff, skip_item, skip_lane, lane_out);
+    if (t != 0.0f) {
+        Hit h;
+        h.dist = t;
+        h.item = item;
+        h.lane = lane_out;
+        hit_normal<N, false>(sc, h, o, d, no, nd);           // (tracer.hpp:431-437, 583-596)
+    }
+    return t;
+}
+
+// The reference's `checked` list (tracer.hpp:782,832,1166) kept exactly: one bit per primitive for this lane.
+struct Checked {
+    uint32_t *bits;          // this lane's column: word w at bits[w * stride]
+    long long stride;
+    int words, n_batches, n_triangles;
+};
+__device__ __forceinline__ void checked_reset(const Checked &c) {
+    for (int w = 0; w < c.words; ++w) c.bits[(long long)w * c.stride] = 0u;
+}
+__device__ __forceinline__ bool checked_seen(const Checked &c, int item) {
+    const int kind = item & 3, idx = item >> 2;
+    const int id = kind == 0 ? idx : (kind == 1 ? c.n_batches + idx : c.n_batches + c.n_triangles + idx);
+    uint32_t *p = c.bits + (long long)(id >> 5) * c.stride;
+    const uint32_t v = *p, m = 1u << (id & 31);
+    *p = v | m;
+    return (v & m) != 0u;
+}
+
 // kd_leaf<Store,true>::intersects (tracer.hpp:977-1086) with transparent hits: first loop until an opaque
 // hit, then "is there anything closer?", then trim_intersections with the LAST test's dist (:1084).
-template <int N>
+// ALIAS: the hit's normal ray (hn_o, hn_d) is carried along and written to exactly as the reference writes to
+// o_hit.normal; `ck` is the exact `checked` list.  Otherwise the normal is worked out from the hit afterwards.
+template <int N, bool ALIAS>
 __device__ __noinline__ bool leaf_closest_t(const NtCompositeDev &sc, const WaveLds &w, int lane, int start, int count, const float (&o)[N],
-                                            const float (&d)[N], int skip_item, int skip_lane, Hit &hit, TList &th) {
+                                            const float (&d)[N], int skip_item, int skip_lane, Hit &hit, TList &th, const Checked &ck,
+                                            float (&hn_o)[N], float (&hn_d)[N]) {
     const int h_start = th.n;
     bool found = false;
     float dist_last = 0.0f;
     for (int i = 0; i < count; ++i) {
         const int item = sc.items[start + i];
         if ((item & 3) != 0 && item == skip_item) continue;
-        if (mbox_seen(w, lane, item)) continue;
+        if (ALIAS ? checked_seen(ck, item) : mbox_seen(w, lane, item)) continue;
         int l;
-        const float t = test_item<N>(sc, item, o, d, hit.dist, skip_item, skip_lane, l);
+        float t;
+        if (ALIAS) {
+            if (!found) {
+                // first loop: the test writes to o_hit.normal itself (tracer.hpp:1001,1020)
+                t = test_item_marks<N>(sc, item, o, d, hit.dist, skip_item, skip_lane, l, hn_o, hn_d);
+            } else {
+                // "is there anything closer?": a separate new_normal, copied on an opaque hit (:1037-1082)
+                float nn_o[N], nn_d[N];
+                t = test_item_marks<N>(sc, item, o, d, hit.dist, skip_item, skip_lane, l, nn_o, nn_d);
+                if (t != 0.0f && material_of(sc, item, l)[6] >= 1.0f) {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) { hn_o[k] = nn_o[k]; hn_d[k] = nn_d[k]; }
+                }
+            }
+        } else {
+            t = test_item<N>(sc, item, o, d, hit.dist, skip_item, skip_lane, l);
+        }
         dist_last = t;
         if (t != 0.0f) {
             if (material_of(sc, item, l)[6] >= 1.0f) {
@@ -925,14 +1063,16 @@ __device__ __noinline__ bool leaf_closest_t(const NtCompositeDev &sc, const Wave
 // kd_node_intersection::operator() with the transparent-list trims (tracer.hpp:1211-1231).  Stack entries:
 // branch index | list size at the push << 24; NT_STK_MARK marks "far side of this branch is being walked
 // after a near hit: trim the list when it returns with a closer hit".
-template <int N>
+template <int N, bool ALIAS>
 __device__ __noinline__ bool trace_closest_t(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
-                                             float t_near, int skip_item, int skip_lane, Hit &hit, TList &th) {
+                                             float t_near, int skip_item, int skip_lane, Hit &hit, TList &th, const Checked &ck,
+                                             float (&hn_o)[N], float (&hn_d)[N]) {
     hit.dist = FLT_MAX;
     hit.item = -1;
     hit.lane = -1;
     th.n = 0;
-    mbox_reset(w, lane);
+    if (ALIAS) checked_reset(ck);
+    else mbox_reset(w, lane);
     int node = sc.root;
     int sp = 0;
     int dirty = 0;
@@ -942,7 +1082,7 @@ __device__ __noinline__ bool trace_closest_t(const NtCompositeDev &sc, const Wav
         while (node >= 0) {
             const NtNode nd = sc.nodes[node];
             if (nd.axis < 0) {
-                if (leaf_closest_t<N>(sc, w, lane, nd.left, nd.right, o, d, skip_item, skip_lane, hit, th)) dirty = sp;
+                if (leaf_closest_t<N, ALIAS>(sc, w, lane, nd.left, nd.right, o, d, skip_item, skip_lane, hit, th, ck, hn_o, hn_d)) dirty = sp;
                 node = -1;
                 break;
             }
@@ -1109,10 +1249,12 @@ struct TFrame {
     Color3 r;                     // colour composited so far
     Color3 spec, r0, c;           // base_color of surface j, waiting for its reflection
     float spec_a, refl;
+    float hn_o[N], hn_d[N];       // ALIAS: o_hit.normal as the walk left it (the normal ray surface 0 is shaded with)
 };
 
-template <int N>
-__device__ __noinline__ Color3 composite_color_t(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&org)[N], const float (&dir)[N]) {
+template <int N, bool ALIAS>
+__device__ __noinline__ Color3 composite_color_t(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&org)[N], const float (&dir)[N],
+                                                 const Checked &ck) {
     TFrame<N> frames[NT_TFRAMES];
     int fp = 0;
     {
@@ -1136,10 +1278,17 @@ __device__ __noinline__ Color3 composite_color_t(const NtCompositeDev &sc, const
             th.n = 0;
             Hit hit;
             hit.item = -1; hit.lane = -1; hit.dist = FLT_MAX;
+            float hn_o[N], hn_d[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) { hn_o[k] = 0.0f; hn_d[k] = 0.0f; }       // ray_intersection starts out zeroed (oracle: memset)
             const float dist = aabb_distance<N>(sc, o, d);
             if (dist >= 0.0f) {
                 setup_ray_table<N>(w, lane, o, d);
-                trace_closest_t<N>(sc, w, lane, o, d, dist, F.skip_item, F.skip_lane, hit, th);
+                trace_closest_t<N, ALIAS>(sc, w, lane, o, d, dist, F.skip_item, F.skip_lane, hit, th, ck, hn_o, hn_d);
+            }
+            if (ALIAS) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) { F.hn_o[k] = hn_o[k]; F.hn_d[k] = hn_d[k]; }
             }
             tl_sort_unique(th);
             F.surf[0].dist = hit.dist;
@@ -1176,7 +1325,13 @@ __device__ __noinline__ Color3 composite_color_t(const NtCompositeDev &sc, const
             Hit hit;
             hit.dist = sf.dist; hit.item = sf.item; hit.lane = sf.lane;
             float no[N], nd[N];
-            hit_normal<N, true>(sc, hit, o, d, no, nd);
+            if (ALIAS && F.j == 0) {
+                // the opaque hit is shaded with o_hit.normal as the walk left it (tracer.hpp:1864)
+#pragma unroll
+                for (int k = 0; k < N; ++k) { no[k] = F.hn_o[k]; nd[k] = F.hn_d[k]; }
+            } else {
+                hit_normal<N, true>(sc, hit, o, d, no, nd);      // transparent hits carry a copy made when they were found
+            }
             const float *m = material_of(sc, hit.item, hit.lane);
             opacity = m[6];
             Color3 light = c3(0.0f, 0.0f, 0.0f), specular = c3(0.0f, 0.0f, 0.0f);
@@ -1270,23 +1425,44 @@ __device__ __noinline__ Color3 composite_color_t(const NtCompositeDev &sc, const
     return result;
 }
 
-template <int N>
-__global__ __launch_bounds__(256) void composite_kernel_t(NtCameraFixed cam, NtCompositeDev sc, NtTarget tg) {
+// ALIAS = false: one block per 16x16 tile (grid = tiles).  ALIAS = true: the blocks stride over the tiles (tiles_x *
+// tiles_y * frames of them), because every resident lane owns a column of the `checked` bitmap and that scratch is sized by
+// the grid, not by the image.
+template <int N, bool ALIAS>
+__global__ __launch_bounds__(256) void composite_kernel_t(NtCameraFixed cam_in, NtCompositeDev sc, NtTarget tg, int tiles_x, int tiles_y, int frames) {
     extern __shared__ float2 lds_raw[];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const WaveLds w = wave_lds(reinterpret_cast<char *>(lds_raw), wv, sc.stack_depth, N);
+    Checked ck;
+    ck.bits = ALIAS ? sc.checked + ((long long)blockIdx.x * 256 + tid) : nullptr;
+    ck.stride = sc.checked_lanes;
+    ck.words = sc.checked_words;
+    ck.n_batches = sc.n_batches;
+    ck.n_triangles = sc.n_triangles;
     int px, py;
     if (tg.colors_out) { px = 0; py = 0; }
     else { px = (wv & 1) * 8 + (lane & 7); py = (wv >> 1) * 8 + (lane >> 3); }
-    const PixelRef pr = locate_pixel<16, 16>(tg, px, py, tid);
-    if (pr.valid) {
-        float org[N], right[N], up[N], fwd[N], dir[N];
-        load_camera<N>(cam, org, right, up, fwd);
-        primary_dir<N>(tg, right, up, fwd, pr.x, pr.y, dir);
-        const Color3 c = composite_color_t<N>(sc, w, lane, org, dir);
-        emit_pixel(tg, pr, c.r, c.g, c.b);
+    const long long total = (long long)tiles_x * tiles_y * frames;
+    for (long long tile = ALIAS ? (long long)blockIdx.x : 0; tile < (ALIAS ? total : 1); tile += gridDim.x) {
+        int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+        if (ALIAS) {
+            bz = (int)(tile / ((long long)tiles_x * tiles_y));
+            const int rem = (int)(tile - (long long)bz * tiles_x * tiles_y);
+            by = rem / tiles_x;
+            bx = rem - by * tiles_x;
+        }
+        const PixelRef pr = locate_pixel_at<16, 16>(tg, bx, by, bz, px, py, tid);
+        if (pr.valid) {
+            NtCameraFixed cam = cam_in;
+            float org[N], right[N], up[N], fwd[N], dir[N];
+            if (cam.buf) cam.buf += (size_t)bz * 4 * N - (size_t)blockIdx.z * 4 * N;        // load_camera indexes by blockIdx.z
+            load_camera<N>(cam, org, right, up, fwd);
+            primary_dir<N>(tg, right, up, fwd, pr.x, pr.y, dir);
+            const Color3 c = composite_color_t<N, ALIAS>(sc, w, lane, org, dir, ck);
+            emit_pixel(tg, pr, c.r, c.g, c.b);
+        }
     }
 }
 
@@ -1959,8 +2135,16 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
     }
     const bool feat = sc.n_point_lights || sc.n_global_lights || sc.any_reflective || sc.has_scalar_prims;
     hipStream_t s = (hipStream_t)li.stream;
+    if (sc.checked && !sc.stats) {
+        // reference-faithful normals: as many blocks as the `checked` scratch has lane columns for, striding over the tiles
+        const long long tiles = (long long)grid.x * grid.y * grid.z;
+        long long blocks = sc.checked_lanes / 256;
+        if (blocks > tiles) blocks = tiles;
+        hipLaunchKernelGGL((composite_kernel_t<N, true>), dim3((unsigned)blocks), dim3(256), lds, s, cf, sc, tg, (int)grid.x, (int)grid.y, (int)grid.z);
+        return 0;
+    }
     if (!sc.all_opaque) {
-        hipLaunchKernelGGL((composite_kernel_t<N>), grid, dim3(256), lds, s, cf, sc, tg);
+        hipLaunchKernelGGL((composite_kernel_t<N, false>), grid, dim3(256), lds, s, cf, sc, tg, (int)grid.x, (int)grid.y, (int)grid.z);
         return 0;
     }
     // scenes with unbatched triangles or solids take the packet walk only as the first of two passes (their hits

@@ -120,6 +120,14 @@ struct NtCompositeDev {
     int n_batches, n_solids;
     int prune;                // 1: closest-hit walks drop subtrees that start clearly beyond the current hit (nt_beyond_hit)
     unsigned long long *stats;  // nullptr or 8 counters (nt_stats order)
+    // Reference-faithful normals (composite_kernel_t<N, true>): the reference's first leaf loop hands o_hit.normal itself to
+    // the primitive tests (tracer.hpp:1001,1020), so which tests run -- its exact `checked` list (:782,:832) -- matters.
+    // One bit per (resident lane, primitive): checked[word * checked_lanes + lane slot]; nullptr selects the "clean"
+    // semantics with the 16-slot mailbox.
+    uint32_t *checked;
+    int checked_words;        // ceil((n_batches + n_triangles + n_solids) / 32)
+    int checked_lanes;        // lane slots = blocks of the launch * 256
+    int n_triangles;
 };
 
 // ---- launchers implemented in nt_var.hip (dispatch) over nt_inst_box.hip / nt_inst_composite.hip ----
@@ -138,6 +146,7 @@ struct NtLaunchInfo {
     int hit_frames;
     float *numer_buf;         // scratch for the packet kernel's plane numerators: numer_frames * n_batches * 4 floats
     int numer_frames;
+    int box_path;             // BoxScene: 1 = fused tile kernels for the scripted formats (default), 0 = cull / box / redo kernels
     uint32_t *cull_buf;       // BoxScene: scratch for the row culling bits, 5 * nframes * row_count * ceil(ceil(width/64)/32) dwords: stretch codes, then redo bits (or nullptr)
 };
 

@@ -187,9 +187,9 @@ struct PixelRef {
     bool valid;
 };
 
-// px,py: position inside the block's BW x BH tile
+// px,py: position inside the BW x BH tile of block (bx, by) of frame bz
 template <int BW, int BH>
-__device__ __forceinline__ PixelRef locate_pixel(const NtTarget &tg, int px, int py, int tid) {
+__device__ __forceinline__ PixelRef locate_pixel_at(const NtTarget &tg, int bx, int by, int bz, int px, int py, int tid) {
     PixelRef r;
     r.valid = false;
     r.x = 0;
@@ -197,7 +197,7 @@ __device__ __forceinline__ PixelRef locate_pixel(const NtTarget &tg, int px, int
     r.offset = 0;
     r.hit_index = 0;
     if (tg.colors_out) {
-        const int idx = (int)blockIdx.x * (BW * BH) + tid;
+        const int idx = bx * (BW * BH) + tid;
         if (idx < tg.probe_count) {
             r.x = tg.probe_xs[idx];
             r.y = tg.probe_ys[idx];
@@ -206,8 +206,8 @@ __device__ __forceinline__ PixelRef locate_pixel(const NtTarget &tg, int px, int
         }
         return r;
     }
-    const int x = (int)blockIdx.x * BW + px;
-    const int row = (int)blockIdx.y * BH + py;      // relative to row_begin
+    const int x = bx * BW + px;
+    const int row = by * BH + py;                    // relative to row_begin
     if (x >= tg.width || row >= tg.row_count) return r;
     const int orow = tg.row_begin + row;             // owned-row index
     int y = orow;
@@ -218,10 +218,15 @@ __device__ __forceinline__ PixelRef locate_pixel(const NtTarget &tg, int px, int
     if (y >= tg.height) return r;
     r.x = x;
     r.y = y;
-    r.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
-    r.hit_index = ((long long)blockIdx.z * tg.row_count + row) * tg.width + x;
+    r.offset = (long long)bz * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
+    r.hit_index = ((long long)bz * tg.row_count + row) * tg.width + x;
     r.valid = true;
     return r;
+}
+
+template <int BW, int BH>
+__device__ __forceinline__ PixelRef locate_pixel(const NtTarget &tg, int px, int py, int tid) {
+    return locate_pixel_at<BW, BH>(tg, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, px, py, tid);
 }
 
 __device__ __forceinline__ void emit_pixel(const NtTarget &tg, const PixelRef &pr, float r, float g, float b) {

@@ -121,22 +121,44 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
 }
 
 // --------------------------------------------------------------------------------------
-// CompositeScene, run-time n (9..64): the var_geometry.hpp path.  Per-lane kernel; the ray's n-vectors
-// (origin, direction, 1/direction, scratch) live in LDS as [k][lane], simplex records are read from global
-// memory component by component.  Feature set of the scripted configurations: batches and unbatched
-// triangles, opaque, camera light; anything else is refused by the host for n > 8.  Operation order is the
-// oracle's, so results are identical to the fixed-N kernels' where both exist.
+// CompositeScene, run-time n (up to 64): the reference's generic `tracern` module (var_geometry.hpp).  Per-lane
+// kernel, the whole of composite_scene::calculate_color for opaque scenes: batches, unbatched triangles, Solids,
+// point / global / camera lights, shadow rays (with _occludes' far-child rule), reflection.  The current ray's n-vectors
+// (origin, 1/direction, direction, a scratch vector) live in LDS as [k][lane] -- every record component is applied to all
+// of them in turn -- while the vectors shading needs once per hit (normal ray, light vector, the saved view direction,
+// a Solid's local ray) sit in per-lane scratch memory.  Simplex and solid records are read component by component.
+// Operation order is the oracle's, so results equal the compile-time-N kernels' where both exist (NTRACER_FORCE_VAR=1).
+// Not here: transparent materials (refused by the host for n > 10).
 // --------------------------------------------------------------------------------------
 struct VarLds {
-    float2 *ray;     // [n][64] (origin, 1/direction)
+    float2 *ray;     // [n][64] (origin, 1/direction; NaN marks direction == 0)
     float *dv;       // [n][64] direction
-    float *ps;       // [n][64] scratch: pside / camera rows
+    float *ps;       // [n][64] scratch: pside
     int *stack;      // [depth][64]
     int *mbox;       // [NT_MBOX][64]
 };
 
 __device__ __forceinline__ size_t var_lds_bytes(int depth, int n) {
     return (size_t)64 * ((size_t)n * 16 + (size_t)depth * 4 + (size_t)NT_MBOX * 4);
+}
+
+struct VarCtx {
+    const NtCompositeDev &sc;
+    VarLds L;
+    WaveLds w;
+    int n, lane;
+};
+
+#define VO(k) (cx.L.ray[(k) * 64 + cx.lane].x)       // origin[k] of the current ray
+#define VD(k) (cx.L.dv[(k) * 64 + cx.lane])          // direction[k]
+
+// make (o, d) the current ray: origin, direction and invdir = 1/direction (tracer.hpp:1174)
+__device__ __forceinline__ void var_set_ray(const VarCtx &cx, const float *o, const float *d) {
+    for (int k = 0; k < cx.n; ++k) {
+        const float dk = d[k];
+        cx.L.dv[k * 64 + cx.lane] = dk;
+        cx.L.ray[k * 64 + cx.lane] = make_float2(o[k], dk != 0.0f ? 1.0f / dk : __int_as_float(0x7fc00000));
+    }
 }
 
 // triangle_batch::intersects lane / triangle::intersects with run-time n (tracer.hpp:411-440, 561-581)
@@ -170,6 +192,437 @@ __device__ __forceinline__ float simplex_var(const float *__restrict__ rec, int 
     return ok ? t : 0.0f;
 }
 
+// solid::intersects (tracer.hpp:251-276) on the current ray, hypercube_intersects / hypersphere_intersects (:126-173) on
+// the local ray.  want_normal: (no, nd) receive the world-space normal ray.
+__device__ __noinline__ float solid_var(const VarCtx &cx, int idx, float cutoff, bool want_normal, float *no, float *nd) {
+    const int n = cx.n;
+    const float *orient = cx.sc.solid_recs + (size_t)idx * (2 * n * n + n);
+    const float *inv = orient + n * n;
+    const float *pos = inv + n * n;
+    float lo[NT_DEV_MAX_DIM], ld[NT_DEV_MAX_DIM], ln_o[NT_DEV_MAX_DIM], ln_d[NT_DEV_MAX_DIM];
+    for (int i = 0; i < n; ++i) {
+        float so = 0.0f, sd = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float m = inv[i * n + k];
+            const float po = m * VO(k), pd = m * VD(k);
+            so = k == 0 ? po : so + po;
+            sd = k == 0 ? pd : sd + pd;
+        }
+        lo[i] = so - pos[i];
+        ld[i] = sd;
+    }
+    float dist = 0.0f;
+    if (cx.sc.solid_types[idx] == 1) {
+        for (int i = 0; i < n; ++i) {
+            const float di = ld[i];
+            if (di == 0.0f) continue;
+            const float s = di < 0.0f ? 1.0f : -1.0f;
+            const float t = (s - lo[i]) / di;
+            if (!(t > 0.0f)) continue;
+            bool ok = true;
+            for (int j = 0; j < n; ++j) {
+                if (j != i) {
+                    const float p = ld[j] * t + lo[j];
+                    ln_o[j] = p;
+                    if (fabsf(p) > (1.0f + NT_FUZZ)) { ok = false; break; }
+                }
+            }
+            if (!ok) continue;
+            if (t >= cutoff) return 0.0f;
+            dist = t;
+            ln_o[i] = s;
+            for (int j = 0; j < n; ++j) ln_d[j] = j == i ? s : 0.0f;
+            break;
+        }
+    } else {
+        float a = 0.0f, b = 0.0f, c = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float pa = ld[k] * ld[k], pb = ld[k] * lo[k], pc = lo[k] * lo[k];
+            a = k == 0 ? pa : a + pa;
+            b = k == 0 ? pb : b + pb;
+            c = k == 0 ? pc : c + pc;
+        }
+        b = 2.0f * b;
+        c = c - 1.0f;
+        const float disc = b * b - 4.0f * a * c;
+        if (disc < 0.0f) return 0.0f;
+        const float t = (-b - sqrtf(disc)) / (2.0f * a);
+        if (t <= 0.0f || t >= cutoff) return 0.0f;
+        dist = t;
+        for (int j = 0; j < n; ++j) { ln_o[j] = lo[j] + ld[j] * t; ln_d[j] = ln_o[j]; }
+    }
+    if (dist == 0.0f) return 0.0f;
+    if (want_normal) {
+        for (int i = 0; i < n; ++i) ln_o[i] = ln_o[i] + pos[i];
+        for (int i = 0; i < n; ++i) {
+            float so = 0.0f, sd = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                const float m = orient[i * n + k];
+                const float po = m * ln_o[k], pd = m * ln_d[k];
+                so = k == 0 ? po : so + po;
+                sd = k == 0 ? pd : sd + pd;
+            }
+            no[i] = so;
+            nd[i] = sd;
+        }
+    }
+    return dist;
+}
+
+// composite_scene::aabb_distance (tracer.hpp:1892-1918) for the current ray
+__device__ __forceinline__ float aabb_distance_var(const VarCtx &cx) {
+    const int n = cx.n;
+    const float *aabb = cx.sc.aabb;
+    for (int i = 0; i < n; ++i) {
+        const float di = VD(i);
+        if (di == 0.0f) continue;
+        const float face = di > 0.0f ? aabb[i] : aabb[n + i];
+        float dist = (face - VO(i)) / di;
+        int skip = i;
+        if (dist < 0.0f) { dist = 0.0f; skip = -1; }
+        bool ok = true;
+        for (int j = 0; j < n; ++j) {
+            if (j != skip) {
+                const float p = VD(j) * dist + VO(j);
+                if (p >= aabb[n + j] || p <= aabb[j]) { ok = false; break; }
+            }
+        }
+        if (ok) return dist;
+    }
+    return -1.0f;
+}
+
+// kd_leaf<Store,true>::intersects for all-opaque scenes (see leaf_closest in nt_composite.hpp)
+__device__ __forceinline__ bool leaf_closest_var(const VarCtx &cx, int start, int count, int skip_item, int skip_lane, Hit &hit) {
+    const NtCompositeDev &sc = cx.sc;
+    bool improved = false;
+    for (int i = 0; i < count; ++i) {
+        const int item = sc.items[start + i];
+        const int kind = item & 3, idx = item >> 2;
+        if (mbox_seen(cx.w, cx.lane, item)) continue;
+        if (kind == 0) {
+            const int sl = item == skip_item ? skip_lane : -1;
+            float min_t = hit.dist;
+            int r = -1;
+            for (int l = 0; l < NT_DEV_BATCH; ++l) {
+                const float t = simplex_var(sc.batch_recs + ((size_t)idx * NT_DEV_BATCH + l) * sc.rec_stride, cx.n, cx.L, cx.lane, false, 0.0f);
+                if (l != sl && t != 0.0f && t < min_t) { min_t = t; r = l; }
+            }
+            if (r >= 0) { hit.dist = min_t; hit.item = item; hit.lane = r; improved = true; }
+        } else if (item != skip_item) {
+            float t;
+            if (kind == 1) t = simplex_var(sc.tri_recs + (size_t)idx * sc.rec_stride, cx.n, cx.L, cx.lane, true, hit.dist);
+            else t = solid_var(cx, idx, hit.dist, false, nullptr, nullptr);
+            if (t != 0.0f) { hit.dist = t; hit.item = item; hit.lane = -1; improved = true; }
+        }
+    }
+    return improved;
+}
+
+// kd_node_intersection::operator() (tracer.hpp:1179-1243): the continuation stack of trace_closest (nt_composite.hpp)
+__device__ __noinline__ bool trace_closest_var(const VarCtx &cx, float t_near, int skip_item, int skip_lane, Hit &hit) {
+    const NtCompositeDev &sc = cx.sc;
+    const WaveLds &w = cx.w;
+    const int lane = cx.lane;
+    hit.dist = FLT_MAX;
+    hit.item = -1;
+    hit.lane = -1;
+    mbox_reset(w, lane);
+    int node = sc.root, sp = 0, dirty = 0;
+    float t_far = FLT_MAX;
+    const int max_sp = sc.stack_depth;
+    for (;;) {
+        while (node >= 0) {
+            if (sc.prune && nt_beyond_hit(hit.dist, t_near)) { node = -1; break; }
+            const NtNode nd = sc.nodes[node];
+            if (nd.axis < 0) {
+                if (leaf_closest_var(cx, nd.left, nd.right, skip_item, skip_lane, hit)) dirty = sp;
+                node = -1;
+                break;
+            }
+            const float2 oi = w.ray[nd.axis * 64 + lane];
+            const float oa = oi.x, inv = oi.y;
+            if (inv == inv) {
+                if (oa == nd.split) { node = inv > 0.0f ? nd.right : nd.left; continue; }
+                const float t = (nd.split - oa) * inv;
+                const bool gt = oa > nd.split;
+                const int n_near = gt ? nd.right : nd.left;
+                const int n_far = gt ? nd.left : nd.right;
+                if (t < 0.0f || t > t_far) { node = n_near; continue; }
+                if (t < t_near) { node = n_far; continue; }
+                if (n_near >= 0) {
+                    if (sp < max_sp) { w.stack[sp * 64 + lane] = node; ++sp; }
+                    t_far = t;
+                    node = n_near;
+                    continue;
+                }
+                node = n_far;
+                t_near = t;
+                continue;
+            }
+            node = oa >= nd.split ? nd.right : nd.left;
+        }
+        bool resumed = false;
+        while (sp > 0) {
+            --sp;
+            const NtNode nd = sc.nodes[w.stack[sp * 64 + lane]];
+            bool gt;
+            const float t = branch_t(w, lane, nd, gt);
+            const int far = gt ? nd.left : nd.right;
+            const bool near_hit = sp < dirty;
+            if (dirty > sp) dirty = sp;
+            if ((near_hit && hit.dist <= t) || far < 0) continue;
+            node = far;
+            t_near = t;
+            t_far = FLT_MAX;
+            if (sp > 0) {
+                const NtNode up = sc.nodes[w.stack[(sp - 1) * 64 + lane]];
+                bool g2;
+                t_far = branch_t(w, lane, up, g2);
+            }
+            resumed = true;
+            break;
+        }
+        if (!resumed) break;
+    }
+    return hit.item >= 0;
+}
+
+// kd_leaf::occludes (tracer.hpp:1088-1124), all-opaque scenes
+__device__ __forceinline__ bool leaf_occludes_var(const VarCtx &cx, int start, int count, float ldistance, int skip_item, int skip_lane) {
+    const NtCompositeDev &sc = cx.sc;
+    for (int i = 0; i < count; ++i) {
+        const int item = sc.items[start + i];
+        const int kind = item & 3, idx = item >> 2;
+        if (kind == 0) {
+            const int sl = item == skip_item ? skip_lane : -1;
+            bool any = false;
+            for (int l = 0; l < NT_DEV_BATCH; ++l) {
+                const float t = simplex_var(sc.batch_recs + ((size_t)idx * NT_DEV_BATCH + l) * sc.rec_stride, cx.n, cx.L, cx.lane, false, 0.0f);
+                any = any || (l != sl && t != 0.0f && t < ldistance);
+            }
+            if (any) return true;
+        } else if (item != skip_item) {
+            float t;
+            if (kind == 1) t = simplex_var(sc.tri_recs + (size_t)idx * sc.rec_stride, cx.n, cx.L, cx.lane, true, ldistance);
+            else t = solid_var(cx, idx, ldistance, false, nullptr, nullptr);
+            if (t != 0.0f) return true;
+        }
+    }
+    return false;
+}
+
+// _occludes (tracer.hpp:1258-1307) for the current ray, `if(t < ldistance) return false;` (:1298) included
+__device__ __noinline__ bool trace_occluded_var(const VarCtx &cx, float ldistance, int skip_item, int skip_lane) {
+    const NtCompositeDev &sc = cx.sc;
+    const WaveLds &w = cx.w;
+    const int lane = cx.lane;
+    int node = sc.root, sp = 0;
+    float t_near = 0.0f, t_far = FLT_MAX;
+    const int max_sp = sc.stack_depth;
+    for (;;) {
+        while (node >= 0) {
+            const NtNode nd = sc.nodes[node];
+            if (nd.axis < 0) {
+                if (leaf_occludes_var(cx, nd.left, nd.right, ldistance, skip_item, skip_lane)) return true;
+                node = -1;
+                break;
+            }
+            const float2 oi = w.ray[nd.axis * 64 + lane];
+            const float oa = oi.x, inv = oi.y;
+            if (inv == inv) {
+                if (oa == nd.split) { node = inv > 0.0f ? nd.right : nd.left; continue; }
+                const float t = (nd.split - oa) * inv;
+                const bool gt = oa > nd.split;
+                const int n_near = gt ? nd.right : nd.left;
+                const int n_far = gt ? nd.left : nd.right;
+                if (t < 0.0f || t > t_far) { node = n_near; continue; }
+                if (t < t_near) { node = n_far; continue; }
+                if (n_near >= 0) {
+                    if (sp < max_sp) { w.stack[sp * 64 + lane] = node; ++sp; }
+                    t_far = t;
+                    node = n_near;
+                    continue;
+                }
+                if (t < ldistance) { node = -1; break; }
+                t_near = t;
+                node = n_far;
+                continue;
+            }
+            node = oa >= nd.split ? nd.right : nd.left;
+        }
+        bool resumed = false;
+        while (sp > 0) {
+            --sp;
+            const NtNode nd = sc.nodes[w.stack[sp * 64 + lane]];
+            bool gt;
+            const float t = branch_t(w, lane, nd, gt);
+            const int far = gt ? nd.left : nd.right;
+            if (t < ldistance || far < 0) continue;
+            node = far;
+            t_near = t;
+            t_far = FLT_MAX;
+            if (sp > 0) {
+                const NtNode up = sc.nodes[w.stack[(sp - 1) * 64 + lane]];
+                bool g2;
+                t_far = branch_t(w, lane, up, g2);
+            }
+            resumed = true;
+            break;
+        }
+        if (!resumed) return false;
+    }
+}
+
+__device__ __forceinline__ float dot_var(int n, const float *a, const float *b) {
+    float s = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        const float p = a[k] * b[k];
+        s = k == 0 ? p : s + p;
+    }
+    return s;
+}
+
+// append_specular (tracer.hpp:1701-1707)
+__device__ __forceinline__ void append_specular_var(int n, Color3 &c, float &a, const float *m, Color3 light_c, const float *target, const float *normal,
+                                                    const float *light_dir) {
+    float tmp[NT_DEV_MAX_DIM];
+    for (int k = 0; k < n; ++k) tmp[k] = light_dir[k] - target[k];
+    const float len = sqrtf(dot_var(n, tmp, tmp));
+    for (int k = 0; k < n; ++k) tmp[k] = tmp[k] / len;
+    const float base = powf(dot_var(n, normal, tmp), m[9]) * m[8];
+    c = cadd(c, cscale(cscale(cmul(c3p(m + 3), light_c), base), (1.0f - a)));
+    a += base * (1.0f - a);
+    c = cscale(c, a);
+}
+
+// ray_color + base_color (tracer.hpp:1768-1883), the reflection recursion as a level stack (see composite_color).
+// On entry the primary ray is the current ray.
+__device__ __noinline__ Color3 composite_color_var(const VarCtx &cx) {
+    const NtCompositeDev &sc = cx.sc;
+    const int n = cx.n;
+    Level levels[NT_DEV_MAX_REFLECT];
+    int depth = 0;
+    int skip_item = -1, skip_lane = -1;
+    Color3 result;
+    float dir[NT_DEV_MAX_DIM], no[NT_DEV_MAX_DIM], nd[NT_DEV_MAX_DIM], lv[NT_DEV_MAX_DIM];
+    for (;;) {
+        // ---- ray_color (tracer.hpp:1856-1883)
+        Hit hit;
+        hit.dist = FLT_MAX; hit.item = -1; hit.lane = -1;
+        bool found = false;
+        const float dist0 = aabb_distance_var(cx);
+        if (dist0 >= 0.0f) found = trace_closest_var(cx, dist0, skip_item, skip_lane, hit);
+        if (!found) {
+            const float iv = VD(sc.bg_axis);
+            result = iv >= 0.0f ? cadd(cscale(c3p(sc.bg1), iv), cscale(c3p(sc.bg2), 1.0f - iv))
+                                : cadd(cscale(c3p(sc.bg3), -iv), cscale(c3p(sc.bg2), 1.0f + iv));
+            break;
+        }
+        // ---- the hit's normal ray (what the reference's tests stored in o_hit.normal)
+        const int kind = hit.item & 3, idx = hit.item >> 2;
+        for (int k = 0; k < n; ++k) dir[k] = VD(k);
+        if (kind != 2) {
+            const float *rec = kind == 0 ? sc.batch_recs + ((size_t)idx * NT_DEV_BATCH + hit.lane) * sc.rec_stride
+                                         : sc.tri_recs + (size_t)idx * sc.rec_stride;
+            float denom = 0.0f, fsq = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                const float fn = rec[1 + k];
+                const float pd = fn * dir[k];
+                denom = k == 0 ? pd : denom + pd;
+                fsq = k == 0 ? fn * fn : fsq + fn * fn;
+            }
+            const float flen = sqrtf(fsq);
+            for (int k = 0; k < n; ++k) {
+                no[k] = VO(k) + hit.dist * dir[k];
+                const float u = rec[1 + k] / flen;
+                nd[k] = denom > 0.0f ? -u : u;
+            }
+        } else {
+            solid_var(cx, idx, FLT_MAX, true, no, nd);
+        }
+        // ---- base_color (tracer.hpp:1768-1854)
+        const float *m = material_of(sc, hit.item, hit.lane);
+        Color3 light = c3(0.0f, 0.0f, 0.0f), specular = c3(0.0f, 0.0f, 0.0f);
+        float spec_a = 0.0f;
+        for (int li = 0; li < sc.n_point_lights; ++li) {
+            const float *pos = sc.pl_pos + (size_t)li * n;
+            const Color3 plc = c3p(sc.pl_color + 3 * li);
+            for (int k = 0; k < n; ++k) lv[k] = no[k] - pos[k];
+            const float ldist = sqrtf(dot_var(n, lv, lv));
+            for (int k = 0; k < n; ++k) lv[k] = lv[k] / ldist;
+            const float sine = dot_var(n, nd, lv);
+            if (sine > 0.0f) {
+                const float strength = (float)(1.0 / pow((double)ldist, (double)(n - 1)));
+                if (sc.shadows) {
+                    if (fmaxf(plc.r, fmaxf(plc.g, plc.b)) * strength * sine > NT_LIGHT_THRESHOLD) {
+                        var_set_ray(cx, no, lv);
+                        if (!trace_occluded_var(cx, ldist, hit.item, hit.lane)) {
+                            const Color3 filtered = cscale(plc, strength);
+                            light = cadd(light, cscale(filtered, sine));
+                            if (m[8] != 0.0f) append_specular_var(n, specular, spec_a, m, filtered, dir, nd, lv);
+                        }
+                    }
+                } else {
+                    light = cadd(light, cscale(cscale(plc, strength), sine));
+                }
+            }
+        }
+        for (int li = 0; li < sc.n_global_lights; ++li) {
+            const float *gd = sc.gl_dir + (size_t)li * n;
+            const Color3 glc = c3p(sc.gl_color + 3 * li);
+            const float sine = -dot_var(n, nd, gd);
+            if (sine > 0.0f) {
+                if (sc.shadows) {
+                    for (int k = 0; k < n; ++k) lv[k] = -gd[k];
+                    var_set_ray(cx, no, lv);
+                    if (!trace_occluded_var(cx, FLT_MAX, hit.item, hit.lane)) {
+                        light = cadd(light, cscale(glc, sine));
+                        if (m[8] != 0.0f) append_specular_var(n, specular, spec_a, m, glc, dir, nd, lv);
+                    }
+                } else {
+                    light = cadd(light, cscale(glc, sine));
+                }
+            }
+        }
+        const float sine = -dot_var(n, dir, nd);
+        if (sc.camera_light && sine > 0.0f) {
+            light = cadd(light, c3(sine, sine, sine));
+            if (m[8] != 0.0f) {
+                const float base = powf(sine, m[9]) * m[8];
+                specular = cadd(specular, cscale(cscale(c3p(m + 3), base), (1.0f - spec_a)));
+                spec_a += base * (1.0f - spec_a);
+                specular = cscale(specular, spec_a);
+            }
+        }
+        const Color3 r0 = cadd(c3p(sc.ambient), cmul(c3p(m), light));
+        if (m[7] != 0.0f && depth < sc.max_reflect_depth && depth < NT_DEV_MAX_REFLECT) {
+            Level &Lv = levels[depth];
+            Lv.spec = specular;
+            Lv.spec_a = spec_a;
+            Lv.r0 = r0;
+            Lv.c = c3p(m);
+            Lv.refl = m[7];
+            const float f = -2.0f * sine;
+            for (int k = 0; k < n; ++k) dir[k] = dir[k] - nd[k] * f;
+            var_set_ray(cx, no, dir);
+            skip_item = hit.item;
+            skip_lane = hit.lane;
+            ++depth;
+            continue;
+        }
+        result = cadd(specular, cscale(r0, 1.0f - spec_a));
+        break;
+    }
+    while (depth > 0) {
+        --depth;
+        const Level &Lv = levels[depth];
+        const Color3 r = cadd(cscale(cmul(Lv.c, result), Lv.refl), cscale(Lv.r0, 1.0f - Lv.refl));
+        result = cadd(Lv.spec, cscale(r, 1.0f - Lv.spec_a));
+    }
+    return result;
+}
+
 __global__ __launch_bounds__(64) void composite_kernel_var(NtCamera cam, NtCompositeDev sc, NtTarget tg, int n) {
     extern __shared__ float2 lds_raw[];
     const int lane = (int)threadIdx.x;
@@ -191,7 +644,7 @@ __global__ __launch_bounds__(64) void composite_kernel_var(NtCamera cam, NtCompo
     if (!pr.valid) return;
     const float *c = cam.buf ? cam.buf + (size_t)blockIdx.z * 4 * n : nullptr;
 
-    // ---- primary ray (tracer.hpp:60-76), direction into LDS
+    // ---- primary ray (tracer.hpp:60-76) becomes the current ray
     const float sx = tg.fovI * ((float)pr.x - tg.half_w);
     const float sy = tg.fovI * ((float)pr.y - tg.half_h);
     float sq = 0.0f;
@@ -210,151 +663,13 @@ __global__ __launch_bounds__(64) void composite_kernel_var(NtCamera cam, NtCompo
         const float ok_ = c ? c[k] : cam.inl[k];
         L.ray[k * 64 + lane] = make_float2(ok_, dk != 0.0f ? 1.0f / dk : __int_as_float(0x7fc00000));
     }
-
-    // ---- aabb_distance (tracer.hpp:1892-1918)
-    float dist0 = -1.0f;
-    for (int i = 0; i < n && dist0 < 0.0f; ++i) {
-        const float di = L.dv[i * 64 + lane];
-        if (di == 0.0f) continue;
-        const float oi = L.ray[i * 64 + lane].x;
-        const float face = di > 0.0f ? sc.aabb[i] : sc.aabb[n + i];
-        float dist = (face - oi) / di;
-        int skip = i;
-        if (dist < 0.0f) { dist = 0.0f; skip = -1; }
-        bool ok = true;
-        for (int j = 0; j < n; ++j) {
-            if (j != skip) {
-                const float p = L.dv[j * 64 + lane] * dist + L.ray[j * 64 + lane].x;
-                if (p >= sc.aabb[n + j] || p <= sc.aabb[j]) { ok = false; break; }
-            }
-        }
-        if (ok) dist0 = dist;
-    }
-
-    Hit hit;
-    hit.dist = FLT_MAX; hit.item = -1; hit.lane = -1;
-    if (dist0 >= 0.0f) {
-        // ---- kd_node_intersection (same continuation stack as trace_closest)
-        mbox_reset(w, lane);
-        int node = sc.root, sp = 0, dirty = 0;
-        float t_near = dist0, t_far = FLT_MAX;
-        for (;;) {
-            while (node >= 0) {
-                if (sc.prune && nt_beyond_hit(hit.dist, t_near)) { node = -1; break; }
-                const NtNode nd = sc.nodes[node];
-                if (nd.axis < 0) {
-                    bool improved = false;
-                    for (int i = 0; i < nd.right; ++i) {
-                        const int item = sc.items[nd.left + i];
-                        if (mbox_seen(w, lane, item)) continue;
-                        const int kind = item & 3, idx = item >> 2;
-                        if (kind == 0) {
-                            float min_t = hit.dist;
-                            int r = -1;
-                            for (int l = 0; l < NT_DEV_BATCH; ++l) {
-                                const float t = simplex_var(sc.batch_recs + ((size_t)idx * NT_DEV_BATCH + l) * sc.rec_stride, n, L, lane, false, 0.0f);
-                                if (t != 0.0f && t < min_t) { min_t = t; r = l; }
-                            }
-                            if (r >= 0) { hit.dist = min_t; hit.item = item; hit.lane = r; improved = true; }
-                        } else {
-                            const float t = simplex_var(sc.tri_recs + (size_t)idx * sc.rec_stride, n, L, lane, true, hit.dist);
-                            if (t != 0.0f) { hit.dist = t; hit.item = item; hit.lane = -1; improved = true; }
-                        }
-                    }
-                    if (improved) dirty = sp;
-                    node = -1;
-                    break;
-                }
-                const float2 oi = L.ray[nd.axis * 64 + lane];
-                const float oa = oi.x, inv = oi.y;
-                if (inv == inv) {
-                    if (oa == nd.split) { node = inv > 0.0f ? nd.right : nd.left; continue; }
-                    const float t = (nd.split - oa) * inv;
-                    const bool gt = oa > nd.split;
-                    const int n_near = gt ? nd.right : nd.left;
-                    const int n_far = gt ? nd.left : nd.right;
-                    if (t < 0.0f || t > t_far) { node = n_near; continue; }
-                    if (t < t_near) { node = n_far; continue; }
-                    if (n_near >= 0) {
-                        if (sp < depth) { L.stack[sp * 64 + lane] = node; ++sp; }
-                        t_far = t;
-                        node = n_near;
-                        continue;
-                    }
-                    node = n_far;
-                    t_near = t;
-                    continue;
-                }
-                node = oa >= nd.split ? nd.right : nd.left;
-            }
-            bool resumed = false;
-            while (sp > 0) {
-                --sp;
-                const NtNode nd = sc.nodes[L.stack[sp * 64 + lane]];
-                bool gt;
-                const float t = branch_t(w, lane, nd, gt);
-                const int far = gt ? nd.left : nd.right;
-                const bool near_hit = sp < dirty;
-                if (dirty > sp) dirty = sp;
-                if ((near_hit && hit.dist <= t) || far < 0) continue;
-                node = far;
-                t_near = t;
-                t_far = FLT_MAX;
-                if (sp > 0) {
-                    const NtNode up = sc.nodes[L.stack[(sp - 1) * 64 + lane]];
-                    bool g2;
-                    t_far = branch_t(w, lane, up, g2);
-                }
-                resumed = true;
-                break;
-            }
-            if (!resumed) break;
-        }
-    }
-
-    // ---- shading: ray_color's miss branch / base_color with the camera light (tracer.hpp:1829-1853, 1866)
-    Color3 col;
-    if (hit.item < 0) {
-        const float iv = L.dv[sc.bg_axis * 64 + lane];
-        col = iv >= 0.0f ? cadd(cscale(c3p(sc.bg1), iv), cscale(c3p(sc.bg2), 1.0f - iv))
-                         : cadd(cscale(c3p(sc.bg3), -iv), cscale(c3p(sc.bg2), 1.0f + iv));
-    } else {
-        const int kind = hit.item & 3, idx = hit.item >> 2;
-        const float *rec = kind == 0 ? sc.batch_recs + ((size_t)idx * NT_DEV_BATCH + hit.lane) * sc.rec_stride
-                                     : sc.tri_recs + (size_t)idx * sc.rec_stride;
-        float denom = 0.0f, fsq = 0.0f;
-        for (int k = 0; k < n; ++k) {
-            const float fn = rec[1 + k];
-            const float pd = fn * L.dv[k * 64 + lane];
-            denom = k == 0 ? pd : denom + pd;
-            fsq = k == 0 ? fn * fn : fsq + fn * fn;
-        }
-        const float flen = sqrtf(fsq);
-        float dn = 0.0f;
-        for (int k = 0; k < n; ++k) {
-            const float u = rec[1 + k] / flen;
-            const float ndk = denom > 0.0f ? -u : u;
-            const float p = L.dv[k * 64 + lane] * ndk;
-            dn = k == 0 ? p : dn + p;
-        }
-        const float sine = -dn;
-        const float *m = material_of(sc, hit.item, hit.lane);
-        Color3 light = c3(0.0f, 0.0f, 0.0f), specular = c3(0.0f, 0.0f, 0.0f);
-        float spec_a = 0.0f;
-        if (sc.camera_light && sine > 0.0f) {
-            light = cadd(light, c3(sine, sine, sine));
-            if (m[8] != 0.0f) {
-                const float base = powf(sine, m[9]) * m[8];
-                specular = cadd(specular, cscale(cscale(c3p(m + 3), base), (1.0f - spec_a)));
-                spec_a += base * (1.0f - spec_a);
-                specular = cscale(specular, spec_a);
-            }
-        }
-        const Color3 r0 = cadd(c3p(sc.ambient), cmul(c3p(m), light));
-        col = cadd(specular, cscale(r0, 1.0f - spec_a));
-    }
+    const VarCtx cx = {sc, L, w, n, lane};
+    const Color3 col = composite_color_var(cx);
     emit_pixel(tg, pr, col.r, col.g, col.b);
 }
+
+#undef VO
+#undef VD
 
 }  // namespace
 
@@ -401,8 +716,8 @@ int nt_launch_composite(const NtLaunchInfo &li, const NtCamera &cam, const NtCom
                 snprintf(nt_launch_error_buf(), NT_LAUNCH_ERROR_LEN, "unsupported dimension %d", li.n);
                 return -2;
             }
-            if (sc.n_point_lights || sc.n_global_lights || sc.any_reflective || sc.n_solids || !sc.all_opaque) {
-                snprintf(nt_launch_error_buf(), NT_LAUNCH_ERROR_LEN, "the run-time-n kernel renders opaque, non-reflective simplices lit by the camera light only");
+            if (!sc.all_opaque) {
+                snprintf(nt_launch_error_buf(), NT_LAUNCH_ERROR_LEN, "the run-time-n kernel does not render transparent materials");
                 return -2;
             }
             // run-time-n kernel: one wave per 8x8 tile (probe mode: 64 probes per block)

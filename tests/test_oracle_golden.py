@@ -113,6 +113,23 @@ def test_feature_scene_matches_reference():
         assert np.median(d) < 1e-6
 
 
+def test_twelve_dimensional_lit_scene_matches_the_generic_reference_module():
+    """lit12_n12: the reference's generic `tracern` (var_geometry.hpp; there is no tracer12) on the facets of a 12-simplex,
+    a Solid cube and sphere, a point and a global light, shadows, reflection depth 2."""
+    g = fx.load("lit12_n12")
+    flat = fx.flat_of(g)
+    assert len(flat["solid_recs"]) == 2 and len(flat["tri_recs"]) == 1 and len(flat["batch_recs"]) == 3
+    p = fx.params_of(g)
+    bad = total = 0
+    for k, f in enumerate(g["frames"]):
+        c = ob.OracleScene(12, g["origins"][f], g["axes"][f], flat=flat, params=p).colors_at(g["xs"], g["ys"], 160, 100)
+        d = np.abs(c - g["colors"][k]).max(axis=1)
+        bad += int((d > TOL).sum())
+        total += len(d)
+        assert np.median(d) < 1e-6
+    assert bad <= 0.005 * total, bad
+
+
 def test_clean_mode_only_differs_where_the_alias_bites():
     g = fx.load("cell600_n4")
     f = g["frames"][1]

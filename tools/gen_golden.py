@@ -526,11 +526,48 @@ def gen_pickles():
     print("wrote pickles", names)
 
 
-def gen_kdtree_known_answer():
-    """Per-stage capture on the 600-cell: nearest-hit records through
-    KDNode.intersects for a fan of rays (advisory, cross-checked in tests
-    against brute force -- see SURVEY section 7 hard part 3)."""
-    pass
+def gen_lit12():
+    """A 12-D scene through the reference's generic module (`tracern`, var_geometry.hpp -- there is no tracer12): the 13
+    facets of a regular 12-simplex (reflective and plain materials alternating) with a Solid cube and a Solid sphere next
+    to it, a point light, a global light, shadows on, reflection depth 2.  Built by the reference's own builder."""
+    n = 12
+    nt = NTracer(n)
+    V = nt.Vector
+    mats = [Material((1, 0.5, 0.5)), Material((0.3, 0.8, 0.4), 1, 0.3, 0.7, 10, (1, 1, 0.7)), Material((0.85, 0.85, 0.9), 1, 0, 0, 8)]
+    pts = [[1.0 if k == i else 0.0 for k in range(n)] for i in range(n)]
+    pts.append([(1 - math.sqrt(n + 1)) / n] * n)
+    centre = [sum(p[k] for p in pts) / (n + 1) for k in range(n)]
+    pts = [[2.5 * (p[k] - centre[k]) for k in range(n)] for p in pts]
+    protos = []
+    for skip in range(n + 1):
+        protos.append(nt.TrianglePrototype([V(*p) for i, p in enumerate(pts) if i != skip], mats[skip % 2]))
+    ax = lambda i: V.axis(i, 1)
+    rot = nt.Matrix.rotation(ax(0), ax(1), 0.4) * nt.Matrix.rotation(ax(2), ax(7), 0.3) * nt.Matrix.scale(0.9)
+    protos.append(nt.SolidPrototype(W.CUBE, V(*([2.6, -1.2, 0.4] + [0.1] * (n - 3))), rot, mats[2]))
+    protos.append(nt.SolidPrototype(W.SPHERE, V(*([-2.4, 1.5, -0.3] + [0.0] * (n - 3))), nt.Matrix.scale(1.1), mats[1]))
+    scene = nt.build_composite_scene(protos)
+    scene.add_light(nt.PointLight(V(*([5.0, 6.0, -7.0, 2.0, 1.0, -1.0, 0.5, 0.0, 2.0, -3.0, 1.0, 0.5])), (9e10, 8e10, 7e10)))
+    scene.add_light(nt.GlobalLight(V(*([0.2, -0.9, 0.3, 0.1, 0.0, 0.1, -0.1, 0.0, 0.05, 0.0, 0.1, -0.05])).unit(), (0.4, 0.4, 0.5)))
+    scene.set_ambient_color((0.02, 0.02, 0.03))
+    scene.set_shadows(True)
+    scene.set_max_reflect_depth(2)
+    fl = Flattener(nt)
+    d = fl.arrays(scene)
+    cam_distance = -2.5 * 4
+    origins, axes = rotation_cameras(nt, cam_distance, frames=40)
+    w, h = 160, 100
+    frames = [0, 7, 19, 33]
+    xs, ys = lattice(w, h, 3, 2, 1, 1)
+    cols = np.zeros((len(frames), len(xs), 3), np.float32)
+    for k, f in enumerate(frames):
+        set_cam(nt, scene, origins[f], axes[f])
+        cols[k] = colors_at(scene, xs, ys, w, h)
+    d.update(scene_params(scene))
+    d.update(origins=origins, axes=axes, cam_distance=np.float32(cam_distance), frames=np.array(frames, np.int32),
+             xs=xs, ys=ys, colors=cols, width=np.int32(w), height=np.int32(h))
+    np.savez_compressed(os.path.join(OUT, "lit12_n12.npz"), **d)
+    print("wrote lit12_n12 nodes", len(d["node_axis"]), "items", len(d["items"]), "batches", len(d["batch_recs"]), "tris", len(d["tri_recs"]),
+          "solids", len(d["solid_recs"]), "hit fraction", float((np.abs(cols[..., 0] - cols[..., 1]) > 1e-6).mean()))
 
 
 if __name__ == "__main__":
@@ -550,6 +587,7 @@ if __name__ == "__main__":
         "simplex10": lambda: gen_polytope("simplex10_n10", ["3"] * 9, 320, 200, [0, 9, 47, 120], (5, 3)),
         # a 5-D cross-polytope-like {3,3,3,4}: 32 facets, fixed<5> module
         "orthoplex5": lambda: gen_polytope("orthoplex5_n5", ["3", "3", "3", "4"], 320, 200, [0, 9, 47, 120], (5, 3)),
+        "lit12": gen_lit12,
     }
     for k, f in jobs.items():
         if a.only is None or k in a.only:
