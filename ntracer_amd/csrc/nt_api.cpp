@@ -81,6 +81,7 @@ struct DeviceState {
     DevBuf hits;                         // primary-hit records between the two passes of a lit render
     DevBuf numer;                        // packet kernel: -(N.o + d) per (frame, simplex)
     DevBuf cull;                         // BoxScene: row culling bits
+    bool cull_clean = false;             // `cull` is all zero (what the fused BoxScene path needs and leaves behind)
     DevBuf checked;                      // reference-faithful normals: the exact `checked` bitmap, one column per resident lane
     // camera tables travel through pinned host memory (a pageable source makes hipMemcpyAsync wait for the copy on the
     // host, which stalls the launch pipeline of back-to-back calls): a ring of slots, each guarded by an event
@@ -547,6 +548,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     li.numer_buf = nullptr;
     li.numer_frames = 0;
     li.cull_buf = nullptr;
+    li.cull_clean = 0;
     li.box_path = 1;
     if (const char *bp = getenv("NTRACER_BOX_PATH")) li.box_path = atoi(bp);
     if (const char *kc = getenv("NTRACER_COMPOSITE_KERNEL")) li.kernel_choice = atoi(kc);
@@ -657,9 +659,21 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             const size_t words = (size_t)(((tg.width + 63) / 64 + 31) / 32);
             // stretch codes (4 words per redo word), 16 rows of padding (box_kernel reads a wave's rows without
             // clamping), redo bits
-            // ... or, for the fused kernels, one 8-byte redo word per tile of 64 x 32 pixels
-            const size_t tiles = (size_t)((tg.width + 63) / 64) * (size_t)((tg.row_count + 31) / 32) * (size_t)job.nframes;
-            if (int e = ds->cull.ensure(std::max(((size_t)5 * job.nframes * tg.row_count + 64) * words * sizeof(uint32_t), tiles * 8))) return e;
+            const size_t need = ((size_t)5 * job.nframes * tg.row_count + 64) * words * sizeof(uint32_t);
+            if (need > ds->cull.cap || !ds->cull.p) ds->cull_clean = false;
+            if (int e = ds->cull.ensure(need)) return e;
+            // The fused kernels keep their redo bitmap at the start of this buffer and leave it zeroed; after anything else
+            // has written there (a fresh allocation, the cull / box / redo kernels) it is zeroed here, in stream order.
+            // (the formats launch_box_fixed sends there: plain RGB of <= 10 bits in one aligned dword, or three plain fp32 channels)
+            const bool fused = li.box_path != 0 && s->n <= NT_MAX_FIXED_DIM && tg.aligned4 &&
+                               ((tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4) || (tg.plain_f32[0] >= 0 && tg.bpp == 12));
+            if (fused && !ds->cull_clean) {
+                HIP_TRY(hipMemsetAsync(ds->cull.p, 0, ds->cull.cap, job.stream));
+                ds->cull_clean = true;
+            } else if (!fused) {
+                ds->cull_clean = false;
+            }
+            li.cull_clean = fused ? 1 : 0;
             li.cull_buf = (uint32_t *)ds->cull.p;
         }
         r = nt_launch_box(li, cam, tg);
@@ -1046,7 +1060,16 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     // a camera table that earlier launches may still read must not be overwritten: grow-only buffer,
     // refilled only after the stream that used it has drained (same-stream ordering)
     if (int r = ds->cams.ensure(cam_floats * sizeof(float))) return r;
-    HIP_TRY(hipMemcpyAsync(ds->cams.p, packed, cam_floats * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    {
+        // NTRACER_CAM_UPLOAD: "kernel" (default) a copy kernel on the launch stream reading the pinned slot in place;
+        // "memcpy" hipMemcpyAsync (copy engine)
+        const char *eu = getenv("NTRACER_CAM_UPLOAD");
+        if (eu && eu[0] == 'm') {
+            HIP_TRY(hipMemcpyAsync(ds->cams.p, packed, cam_floats * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+        } else if (nt_launch_upload(hip_stream, packed, (float *)ds->cams.p, (int)cam_floats)) {
+            return fail(NT_E_DEVICE, "%s", nt_launch_error());
+        }
+    }
     HIP_TRY(hipEventRecord(st->done, (hipStream_t)hip_stream));
     st->in_flight = true;
     const bool stats = opts && opts->collect_stats;

@@ -570,13 +570,17 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
 
 // The stretches box_kernel<N, true> left behind (tg.redo): one wave per (frame, row, word of 32 stretches), every set
 // bit rendered with the complete box_pixel -- classification, box_resolve, box_color.
-template <int N>
+// F32: three plain fp32 channels instead of packed RGB.  ZERO: hand the word back zeroed (the fused path's bitmap is
+// marked with atomic ORs by box_tile_kernel and must be clean when the next launch starts).
+template <int N, bool F32 = false, bool ZERO = false>
 __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarget tg) {
     const int tid = (int)threadIdx.x;
     const int row = (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);
     if (row >= tg.row_count) return;
-    uint32_t todo = tg.redo[((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + blockIdx.x];
+    uint32_t *word = tg.redo + ((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + blockIdx.x;
+    uint32_t todo = *word;
     if (todo == 0u) return;
+    if (ZERO && (tid & 63) == 0) *word = 0u;
     float org[N], right[N], up[N], fwd[N], dir[N];
     load_camera<N>(cam, org, right, up, fwd);
     float margin = fabsf(org[0]);
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
         float sq = dir[0] * dir[0];
 #pragma unroll
         for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-        box_pixel<N, true, false, true>(tg, pr, org, dir, sq, dots, sx, sy, margin);
+        box_pixel<N, !F32, false, true, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin);
     }
 }
 
@@ -739,19 +743,17 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
 // The fused path for the two formats the reference's scripts render into (packed plain RGB of <= 10 bits a channel in
 // one aligned dword -- RGBX8 & co.: F32 = false; three plain fp32 channels, 12-byte pixels: F32 = true):
 //
-//   box_tile_kernel<N, F32, ROWS>       a block = 64 columns x 4*ROWS rows.  Wave 0 first works out the stretch codes of
-//                                       the tile (box_stretch_code, one row per lane) and leaves them in LDS; after the
-//                                       barrier every wave renders its ROWS rows from them with the lean loops.  Rows it
-//                                       cannot settle (code 14, or a lane that needs the reference's face-by-face
-//                                       arithmetic) are recorded in a 16-bit mask per wave: four of them make the
-//                                       tile's 64-bit redo word, [frame][tile row][tile column].
-//   box_redo_tile_kernel<N, F32, ROWS>  same grid; a block whose redo word is zero leaves at once, otherwise its four
-//                                       waves share the marked rows out among themselves (they have the column, hence
-//                                       forward + right*sx, in common) and render them with box_pixel<REDO>.
-// No pre-kernel, no atomics, no scratch besides the redo words (8 bytes per 64 x 4*ROWS pixels).
+//   box_tile_kernel<N, F32, ROWS>   a block = 64 columns x 4*ROWS rows.  One wave first works out the stretch codes of the
+//                                   tile (box_stretch_code, one row per lane) and leaves them in LDS; after the barrier
+//                                   every wave renders its ROWS rows from them with the lean loops.  A row it cannot settle
+//                                   (code 14, or a lane that needs the reference's face-by-face arithmetic) gets its bit
+//                                   set in the redo bitmap, [frame][row][word of 32 stretches], with an atomic OR.
+//   box_redo_kernel<N, F32>         one wave per (frame, row, word): the marked stretches with box_pixel<REDO>; it hands the
+//                                   word back zeroed, so the bitmap is clean for the next launch (the host zeroes it once).
+// No pre-kernel; the only scratch is the bitmap (one bit per 64 pixels).
 // --------------------------------------------------------------------------------------
 template <int N, bool F32, int ROWS>
-__global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarget tg, uint16_t *redo16) {
+__global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
     static_assert(ROWS == 8 || ROWS == 16, "sixteen row codes to a qword");
     constexpr int R = ROWS;
     __shared__ uint32_t s_code[64];
@@ -772,8 +774,9 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
     }
     const int tile_row0 = (int)blockIdx.y * 4 * R;
-    // ---- phase 1: the tile's stretch codes, one row per lane of wave 0
-    if (wv == 0) {
+    // ---- phase 1: the tile's stretch codes, one row per lane of one wave -- a different one from block to block, so that
+    // the extra work does not always land on the same SIMD of a CU
+    if (wv == (int)((blockIdx.x + blockIdx.y + blockIdx.z) & 3u)) {
         uint32_t code = 0u;
         const int trow = tile_row0 + lane;
         if (lane < 4 * R && trow < tg.row_count) {
@@ -799,7 +802,7 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
     }
     __syncthreads();
     const int row0 = tile_row0 + wv * R;
-    uint32_t redo_bits = 0u;                              // rows (bit rr) left to box_redo_tile_kernel
+    uint32_t redo_bits = 0u;                              // rows (bit rr) left to box_redo_kernel
     if (row0 < tg.row_count) {
         unsigned long long rowcodes = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[2 * wv + 1]) << 32) |
                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[2 * wv]);
@@ -960,62 +963,13 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
             if (!box_pixel<N, !F32, true, false, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit)) redo_bits |= 1u << rr;
         }
     }
-    // every wave of the grid writes its part of the tile's redo word: nothing to clear beforehand
-    if (lane == 0) redo16[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wv] = (uint16_t)redo_bits;
-}
-
-template <int N, bool F32, int ROWS>
-__global__ __launch_bounds__(256) void box_redo_tile_kernel(NtCameraFixed cam, NtTarget tg, const unsigned long long *redo64) {
-    constexpr int R = ROWS;
-    unsigned long long todo = redo64[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x];       // uniform: scalar load
-    if (todo == 0ull) return;
-    const int tid = (int)threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float org[N], right[N], up[N], fwd[N], dir[N];
-    load_camera<N>(cam, org, right, up, fwd);
-    float margin = fabsf(org[0]);
-#pragma unroll
-    for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
-    margin = NT_BOX_MARGIN * (1.0f + margin);
-    float dots[4];
-    if (cam.buf) {
-        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
-        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
-    } else {
-        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
-    }
-    int x = (int)blockIdx.x * 64 + (tid & 63);
-    x = x < tg.width ? x : tg.width - 1;            // as in box_tile_kernel
-    const float sx = tg.fovI * ((float)x - tg.half_w);
-    float base[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
-    // the marked rows in order, dealt round-robin to the four waves
-    int ord = 0;
-    while (todo != 0ull) {
-        const int bit = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        if ((ord++ & 3) != wv) continue;
-        const int row = (int)blockIdx.y * 4 * R + (bit >> 4) * R + (bit & 15);       // bit 16w + rr: row rr of wave w
-        const int orow = tg.row_begin + row;
-        int y = orow;
-        if (tg.band_world > 1) {
-            const int band = orow / tg.band_rows;
-            y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+    // mark the rows left over in the redo bitmap (clean on entry: box_redo_kernel zeroes what it has read)
+    if (lane == 0) {
+        while (redo_bits != 0u) {
+            const int rr = __builtin_ctz(redo_bits);
+            redo_bits &= redo_bits - 1u;
+            atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
         }
-        PixelRef pr;
-        pr.x = x;
-        pr.y = y;
-        pr.offset = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? orow : y) * tg.pitch + (long long)x * tg.bpp;
-        pr.hit_index = 0;
-        pr.valid = true;
-        const float sy = tg.fovI * ((float)y - tg.half_h);
-#pragma unroll
-        for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
-        float sq = dir[0] * dir[0];
-#pragma unroll
-        for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-        box_pixel<N, !F32, false, true, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin);
     }
 }
 
@@ -1037,30 +991,24 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     // a channel in one aligned dword, and three plain fp32 channels
     const bool fmt_rgb = tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4;
     const bool fmt_f32 = tg.plain_f32[0] >= 0 && tg.bpp == 12 && tg.aligned4;
-    if (li.cull_buf && !tg.colors_out && BoxRows<N>::value > 1 && (fmt_rgb || fmt_f32) && li.box_path != 0) {
+    if (li.cull_buf && !tg.colors_out && BoxRows<N>::value > 1 && (fmt_rgb || fmt_f32) && li.box_path != 0 && li.cull_clean) {
         hipStream_t st = (hipStream_t)li.stream;
-        // sixteen rows a lane once there are waves to spare (the per-wave set-up is a fifth of the work at eight)
+        // sixteen rows a lane once there are waves to spare (the per-wave set-up is a fifth of the work at eight) -- unless
+        // tiles of 64 rows would hang much further over the bottom of the launch than tiles of 32
         const long long waves8 = (long long)((tg.width + 63) / 64) * ((tg.row_count + 31) / 32) * li.nframes * 4;
         const bool r16 = waves8 >= 64 * 1024;
         const dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + (r16 ? 63 : 31)) / (r16 ? 64 : 32)), (unsigned)li.nframes);
-        uint16_t *r16p = (uint16_t *)li.cull_buf;
-        const unsigned long long *r64p = (const unsigned long long *)li.cull_buf;
+        tg.redo_words = ((tg.width + 63) / 64 + 31) / 32;
+        tg.redo = li.cull_buf;                        // [frame][row][redo_words], all zero between launches
+        const dim3 rgrid((unsigned)tg.redo_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes);
         if (fmt_rgb) {
-            if (r16) {
-                hipLaunchKernelGGL((box_tile_kernel<N, false, 16>), tgrid, dim3(256), 0, st, cf, tg, r16p);
-                hipLaunchKernelGGL((box_redo_tile_kernel<N, false, 16>), tgrid, dim3(256), 0, st, cf, tg, r64p);
-            } else {
-                hipLaunchKernelGGL((box_tile_kernel<N, false, 8>), tgrid, dim3(256), 0, st, cf, tg, r16p);
-                hipLaunchKernelGGL((box_redo_tile_kernel<N, false, 8>), tgrid, dim3(256), 0, st, cf, tg, r64p);
-            }
+            if (r16) hipLaunchKernelGGL((box_tile_kernel<N, false, 16>), tgrid, dim3(256), 0, st, cf, tg);
+            else hipLaunchKernelGGL((box_tile_kernel<N, false, 8>), tgrid, dim3(256), 0, st, cf, tg);
+            hipLaunchKernelGGL((box_redo_kernel<N, false, true>), rgrid, dim3(256), 0, st, cf, tg);
         } else {
-            if (r16) {
-                hipLaunchKernelGGL((box_tile_kernel<N, true, 16>), tgrid, dim3(256), 0, st, cf, tg, r16p);
-                hipLaunchKernelGGL((box_redo_tile_kernel<N, true, 16>), tgrid, dim3(256), 0, st, cf, tg, r64p);
-            } else {
-                hipLaunchKernelGGL((box_tile_kernel<N, true, 8>), tgrid, dim3(256), 0, st, cf, tg, r16p);
-                hipLaunchKernelGGL((box_redo_tile_kernel<N, true, 8>), tgrid, dim3(256), 0, st, cf, tg, r64p);
-            }
+            if (r16) hipLaunchKernelGGL((box_tile_kernel<N, true, 16>), tgrid, dim3(256), 0, st, cf, tg);
+            else hipLaunchKernelGGL((box_tile_kernel<N, true, 8>), tgrid, dim3(256), 0, st, cf, tg);
+            hipLaunchKernelGGL((box_redo_kernel<N, true, true>), rgrid, dim3(256), 0, st, cf, tg);
         }
         return 0;
     }
@@ -1086,7 +1034,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
             hipLaunchKernelGGL((box_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
         }
         if (BoxRows<N>::value > 1)
-            hipLaunchKernelGGL(box_redo_kernel<N>, dim3((unsigned)tg.redo_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes),
+            hipLaunchKernelGGL((box_redo_kernel<N, false, false>), dim3((unsigned)tg.redo_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes),
                                dim3(256), 0, (hipStream_t)li.stream, cf, tg);
     } else {
         hipLaunchKernelGGL((box_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);

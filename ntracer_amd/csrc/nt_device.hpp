@@ -146,10 +146,12 @@ struct NtLaunchInfo {
     int hit_frames;
     float *numer_buf;         // scratch for the packet kernel's plane numerators: numer_frames * n_batches * 4 floats
     int numer_frames;
-    int box_path;             // BoxScene: 1 = fused tile kernels for the scripted formats (default), 0 = cull / box / redo kernels
+    int box_path;             // BoxScene: 1 = fused tile kernel for the scripted formats (default), 0 = cull / box / redo kernels
+    int cull_clean;           // cull_buf is all zero (the fused path's redo bitmap lives at its start)
     uint32_t *cull_buf;       // BoxScene: scratch for the row culling bits, 5 * nframes * row_count * ceil(ceil(width/64)/32) dwords: stretch codes, then redo bits (or nullptr)
 };
 
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 int nt_launch_composite(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg);
+int nt_launch_upload(void *stream, const float *src_pinned, float *dst, int count);
 const char *nt_launch_error();

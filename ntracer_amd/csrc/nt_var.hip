@@ -673,6 +673,20 @@ __global__ __launch_bounds__(64) void composite_kernel_var(NtCamera cam, NtCompo
 
 }  // namespace
 
+// The camera table of a multi-frame launch, from pinned host memory (which the device reads in place) to device memory:
+// a kernel on the launch stream instead of a copy-engine transfer the next kernel would have to wait for across queues.
+namespace {
+__global__ __launch_bounds__(256) void upload_kernel(const float *__restrict__ src, float *__restrict__ dst, int count) {
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i < count) dst[i] = src[i];
+}
+}  // namespace
+
+int nt_launch_upload(void *stream, const float *src_pinned, float *dst, int count) {
+    hipLaunchKernelGGL(upload_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src_pinned, dst, count);
+    return finish_launch("camera upload");
+}
+
 // NTRACER_FORCE_VAR=1: use the run-time-n kernels for every dimension (they are the only ones above
 // NT_DEV_MAX_FIXED; the switch lets tests compare them with the compile-time-N kernels on the same scene)
 static bool force_var() {

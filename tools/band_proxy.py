@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(world, rank, band_rows, steps, warmup, frames=160, n=6, W=1920, H=1080):
+def measure(world, rank, band_rows, steps, warmup, frames=160, n=6, W=1920, H=1080, f32=False):
     import torch
     import ntracer_amd
     from ntracer_amd import _lib, tracern
@@ -28,8 +28,12 @@ def measure(world, rank, band_rows, steps, warmup, frames=160, n=6, W=1920, H=10
     origins = np.ascontiguousarray(g["origins"][:frames], np.float32)
     axes = np.ascontiguousarray(g["axes"][:frames], np.float32)
     scene = tracern.BoxScene(n)
-    fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(8, 1, 0, 0), ntracer_amd.Channel(8, 0, 1, 0),
-                                         ntracer_amd.Channel(8, 0, 0, 1), ntracer_amd.Channel(8, 0, 0, 0)])
+    if f32:
+        fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(32, 1, 0, 0, 0, True), ntracer_amd.Channel(32, 0, 1, 0, 0, True),
+                                             ntracer_amd.Channel(32, 0, 0, 1, 0, True)])
+    else:
+        fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(8, 1, 0, 0), ntracer_amd.Channel(8, 0, 1, 0),
+                                             ntracer_amd.Channel(8, 0, 0, 1), ntracer_amd.Channel(8, 0, 0, 0)])
     fst = fmt._as_struct()
     opts = _lib.NtRenderOpts()
     opts.device = torch.cuda.current_device()
@@ -59,7 +63,7 @@ def measure(world, rank, band_rows, steps, warmup, frames=160, n=6, W=1920, H=10
     t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    return {"world": world, "rank": rank, "band_rows": band_rows, "owned_rows": own, "frames": frames,
+    return {"format": "rgbf32" if f32 else "rgbx8", "n": n, "box_path": os.environ.get("NTRACER_BOX_PATH", "1"), "world": world, "rank": rank, "band_rows": band_rows, "owned_rows": own, "frames": frames,
             "event_us_per_call": round(e0.elapsed_time(e1) * 1e3 / steps, 2), "wall_us_per_call": round(wall * 1e6 / steps, 2),
             "host_issue_us_per_call": round(t_issue * 1e6 / steps, 2)}
 
@@ -71,5 +75,8 @@ if __name__ == "__main__":
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=160)
+    ap.add_argument("--n", type=int, default=6)
+    ap.add_argument("--f32", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(measure(a.world, a.rank, a.band_rows, a.steps, a.warmup)))
+    print(json.dumps(measure(a.world, a.rank, a.band_rows, a.steps, a.warmup, frames=a.frames, n=a.n, f32=a.f32)))
