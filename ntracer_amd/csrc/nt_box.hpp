@@ -239,12 +239,35 @@ __device__ __forceinline__ void emit_f32x3(const NtTarget &tg, long long offset,
     gb = gb > 0.0f ? gb : 0.0f;
     gb = gb < 1.0f ? gb : 1.0f;
     uint32_t vr = __float_as_uint(r), vgb = __float_as_uint(gb);
-    if (!tg.reversed) { vr = bswap32(vr); vgb = bswap32(vgb); }
     uint3 w;
-    w.x = tg.plain_f32[tg.reversed ? 2 : 0] == 0 ? vr : vgb;
-    w.y = tg.plain_f32[1] == 0 ? vr : vgb;
-    w.z = tg.plain_f32[tg.reversed ? 0 : 2] == 0 ? vr : vgb;
+    if (tg.plain_f32[0] == 0 && tg.plain_f32[1] == 1 && tg.plain_f32[2] == 2 && !tg.reversed) {       // (uniform) R, G, B in order
+        w.x = bswap32(vr);
+        w.y = bswap32(vgb);
+        w.z = w.y;
+    } else {
+        if (!tg.reversed) { vr = bswap32(vr); vgb = bswap32(vgb); }
+        w.x = tg.plain_f32[tg.reversed ? 2 : 0] == 0 ? vr : vgb;
+        w.y = tg.plain_f32[1] == 0 ? vr : vgb;
+        w.z = tg.plain_f32[tg.reversed ? 0 : 2] == 0 ? vr : vgb;
+    }
     *reinterpret_cast<uint3 *>(tg.dest + offset) = w;
+}
+
+// sqrtf(x) for x in [2^-96, 2^96): hipcc's correctly rounded square root is v_sqrt_f32 followed by a choice among the
+// result and its two neighbours (two fma residuals), wrapped in a rescaling for x < 2^-96 and a pass-through for 0 and
+// infinity; inside that range the wrapping does nothing, and this is the rest -- the same operations, hence the same float.
+__device__ __forceinline__ float sqrt_in_range(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vp = fmaf(-s_dn, s, x), vs = fmaf(-s_up, s, x);
+    float r = vp <= 0.0f ? s_dn : s;
+    r = vs > 0.0f ? s_up : r;
+    return r;
+}
+// ... for a whole wave: the plain sqrtf unless every lane is inside the range (NaN included in "outside")
+__device__ __forceinline__ float sqrt_wave(float x) {
+    if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f && x < 0x1p96f)) == 0ull) return sqrt_in_range(x);
+    return sqrtf(x);
 }
 
 // One pixel of BoxScene from the unnormalised direction `dir` (|dir|^2 = sq), sx / sy as in the ray source.
@@ -817,8 +840,15 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
         const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < R && row0 + lane < tg.row_count && ly < tg.height);
         const float v_sy = tg.fovI * ((float)ly - tg.half_h);
         const float v_us0 = up[0] * v_sy;
+        // byte offset of row rr: scalar arithmetic when the rows of the wave lie `pitch` apart in the buffer (always, unless
+        // rows dealt in bands go to a full-size frame), otherwise read back from a per-lane table like sy
+        const bool rows_linear = tg.band_world <= 1 || tg.compact;
+        const long long wave_off = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.row_begin + row0) * tg.pitch;
         const long long v_off = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? lorow : ly) * tg.pitch;
         const int v_off_lo = (int)v_off, v_off_hi = (int)(v_off >> 32);
+#define NT_ROW_OFF(rr)                                                                                                      \
+        ((rows_linear ? wave_off + (long long)(rr) * tg.pitch                                                                \
+                      : (((long long)__builtin_amdgcn_readlane(v_off_hi, (rr)) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, (rr)))) + xoff)
         int x = (int)blockIdx.x * 64 + lane;
         x = x < tg.width ? x : tg.width - 1;
         const long long xoff = (long long)x * tg.bpp;
@@ -882,10 +912,17 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
                     todo |= 1ull << (4 * rr);                                     // a lane too close to a rounding boundary
                     continue;
                 }
+                PixelRef pr;
+                pr.offset = NT_ROW_OFF(rr);
+                if (tg.plain_sel != 0u) {
+                    // 8-bit fields: t + 2^23 has round(t) in its low mantissa byte (t < 255.5; the guard keeps t off the
+                    // half-way points, so nearest-even is the reference's rounding), which is the byte v_perm_b32 picks
+                    const uint32_t q = __float_as_uint(t + 8388608.0f);
+                    *reinterpret_cast<uint32_t *>(tg.dest + pr.offset) = __builtin_amdgcn_perm(d0 > 0.0f ? q : 0u, q, tg.plain_sel);
+                    continue;
+                }
                 uint32_t q = (uint32_t)(t + 0.5f);
                 q = q < tg.plain_maxval ? q : tg.plain_maxval;
-                PixelRef pr;
-                pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
                 emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
             }
             while (inner != 0ull) {
@@ -906,21 +943,42 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
                     todo |= 1ull << (4 * rr);
                     continue;
                 }
+                PixelRef pr;
+                pr.offset = NT_ROW_OFF(rr);
+                if (tg.plain_sel != 0u) {
+                    *reinterpret_cast<uint32_t *>(tg.dest + pr.offset) =
+                        __builtin_amdgcn_perm(__float_as_uint(t + 8388608.0f), __float_as_uint(th + 8388608.0f), tg.plain_sel);
+                    continue;
+                }
                 uint32_t qr = (uint32_t)(t + 0.5f), qgb = (uint32_t)(th + 0.5f);
                 qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
                 qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;
-                PixelRef pr;
-                pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
                 emit_plain(tg, pr, qr, qgb);
             }
         } else {
             // ---- fp32 channels: the stored value IS x / sqrtf(sq), so the reference's sum, square root and division are
             // done as they stand -- but on rows whose code says which x it is, nothing else is
-            unsigned long long easy = quick | inner;
-            while (easy != 0ull) {
-                const int rr = __builtin_ctzll(easy) >> 2;
-                easy &= easy - 1ull;
-                const uint32_t code = (uint32_t)(rowcodes >> (4 * rr)) & 15u;          // 0, or K + 1
+            while (quick != 0ull) {
+                // background rows: i = dir[0]; i > 0 ? (i,i,i) : (0,-i,-i) (tracer.hpp:109-113), clamped as channel_value does
+                const int rr = __builtin_ctzll(quick) >> 2;
+                quick &= quick - 1ull;
+                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+#pragma unroll
+                for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+                float sq = dir[0] * dir[0];
+#pragma unroll
+                for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
+                const float in = dir[0] / sqrt_wave(sq);
+                float r, gb, b_;
+                box_background(in, r, gb, b_);
+                const long long off = NT_ROW_OFF(rr);
+                emit_f32x3(tg, off, r, gb);
+            }
+            while (inner != 0ull) {
+                // one face K throughout: sine = d_K * (-sign d_K) <= 0, shade = -sine (tracer.hpp:105-107)
+                const int rr = __builtin_ctzll(inner) >> 2;
+                inner &= inner - 1ull;
+                const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
                 const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
 #pragma unroll
                 for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
@@ -929,19 +987,10 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
                 for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
                 float xk = dir[0];
 #pragma unroll
-                for (int j = 1; j < N; ++j) xk = code == (uint32_t)(j + 1) ? dir[j] : xk;
-                const float in = xk / sqrtf(sq);
-                float r, gb;
-                if (code != 0u) {
-                    const float shade = fabsf(in);          // sine = d_K * (-sign d_K) <= 0, shade = -sine (tracer.hpp:105-107)
-                    r = shade * 1.0f;
-                    gb = shade * 0.5f;
-                } else {
-                    float b_;
-                    box_background(in, r, gb, b_);
-                }
-                const long long off = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
-                emit_f32x3(tg, off, r, gb);
+                for (int j = 1; j < N; ++j) xk = K == (uint32_t)j ? dir[j] : xk;
+                const float shade = fabsf(xk / sqrt_wave(sq));
+                const long long off = NT_ROW_OFF(rr);
+                emit_f32x3(tg, off, shade * 1.0f, shade * 0.5f);
             }
         }
         while (todo != 0ull) {
@@ -952,7 +1001,7 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
             PixelRef pr;
             pr.x = x;
             pr.y = 0;
-            pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+            pr.offset = NT_ROW_OFF(rr);
             pr.hit_index = 0;
             pr.valid = true;
 #pragma unroll
@@ -963,6 +1012,7 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
             if (!box_pixel<N, !F32, true, false, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit)) redo_bits |= 1u << rr;
         }
     }
+#undef NT_ROW_OFF
     // mark the rows left over in the redo bitmap (clean on entry: box_redo_kernel zeroes what it has read)
     if (lane == 0) {
         while (redo_bits != 0u) {
