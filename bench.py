@@ -20,9 +20,14 @@ work is fixed, so scaling is "strong".  The RCCL gather of the finished bands to
 separately after the timed region and reported as gather_ms_per_frame / value_incl_gather (like the
 D2H copy at N = 1 it is a delivery step, not part of `value`).
 
-One JSON line on rank 0, with the `roofline` of the dominant kernel (framebuffer write bytes vs HBM peak)
-and a `cpu_baseline` (the oracle, multi-threaded exactly like the reference's BlockingRenderer, on a
-bounded sample of the same frames).
+One JSON line on rank 0, with the `roofline` of the dominant kernel (framebuffer write bytes vs HBM peak; `roofline.valu`:
+the instruction-issue bound that actually limits these kernels, from the committed SQ counters), `value_rgbf32` (the same
+workload into three fp32 channels -- the format in which "colours within 1e-4" is a statement about the stored values),
+`scaling_proxy` (one rank's share of an 8-GPU run, timed on this GPU) and a `cpu_baseline` (the oracle, multi-threaded
+exactly like the reference's BlockingRenderer, on a bounded sample of the same frames).
+
+Config ids in `extra` are indices into BASELINE.json's `configs` list (0-based: cfg1 = 3-D hypercube 1080p, cfg2 = the
+headline 6-D hypercube, cfg3 = 120-cell, cfg4 = 10-D hypercube 4096x4096).
 """
 import argparse
 import ctypes as C
@@ -37,7 +42,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4                # max clock (MI355X_MICROARCH.md)
+PROFILE = "r02_pmc_summary.json"       # profiles/: rocprofv3 --pmc passes of THIS build (tools/profile_round.sh)
 RGBX8 = [(8, 1, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0, 0, 0)]
+RGBF32 = [(32, 1, 0, 0, 0, True), (32, 0, 1, 0, 0, True), (32, 0, 0, 1, 0, True)]
+
+
+def load_profile():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", PROFILE)))
+    except (OSError, ValueError):
+        return None
+
+
+def valu_bound(call, measured_us):
+    """The instruction-issue bound of a call from the committed SQ counters: VALU (+ scalar) wave-instructions per call, the
+    time they need at the full fp32 rate -- one VALU wave-instruction per SIMD every 2 cycles at 2.4 GHz, which is what the
+    157 TFLOP/s spec figure means for wave64 -- and that time as a fraction of the measured one."""
+    if not call or "valu_wave_insts_per_call" not in call and "SQ_INSTS_VALU" not in call:
+        return None
+    valu = call.get("valu_wave_insts_per_call", call.get("SQ_INSTS_VALU"))
+    salu = call.get("salu_wave_insts_per_call", call.get("SQ_INSTS_SALU"))
+    active = call.get("valu_active_quad_cycles_per_call", call.get("SQ_ACTIVE_INST_VALU"))
+    cycles = call.get("kernel_cycles_per_call", call.get("kernel_cycles"))
+    limited_us = valu / SIMDS * 2.0 / (CLOCK_GHZ * 1e3)
+    out = {"valu_wave_insts": round(valu), "salu_wave_insts": round(salu) if salu else None,
+           "peak": "1 VALU wave-instruction / SIMD / 2 cycles @ 2.4 GHz (= 157 TFLOP/s fp32)", "issue_limited_us": round(limited_us, 2),
+           "measured_us": round(measured_us, 2), "frac": round(limited_us / measured_us, 4),
+           "source": "profiles/" + PROFILE}
+    if active and cycles:
+        # SQ_ACTIVE_INST_VALU: quad-cycles in which a SIMD's VALU was executing (MI355X_MICROARCH.md); half-rate and
+        # transcendental instructions (v_cndmask, v_perm, v_cvt, v_rsq ...) hold it 4 - 8 cycles, cf. tools/micro/valu_rate.hip
+        out["valu_busy_frac_profiled"] = round(active * 4.0 / SIMDS / cycles, 4)
+        out["cycles_per_valu_inst_profiled"] = round(active * 4.0 / valu, 3)
+    return out
 
 
 def main():
@@ -48,6 +87,7 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed headline loop (the target of the rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
     import torch
@@ -185,14 +225,15 @@ def main():
     kernel_us = dev_ms * 1e3 / launches                       # average launch duration (HIP events)
     total_bytes = float(own_rows) * W * fmt.bytes_per_pixel * F * args.steps     # algorithmic: framebuffer write only
     achieved = total_bytes / (dev_ms * 1e-3) / 1e9
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (separate runs; cannot be sampled live)
+    # HBM traffic and instruction counts per call from the committed rocprofv3 PMC passes of this build (separate runs:
+    # counters cannot be sampled live)
     traffic = None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        if world == 1 and prof.get("frames_per_launch") == F:
-            traffic = prof["write_bytes_per_launch"] + prof["fetch_bytes_per_launch_corrected"]
-    except (OSError, ValueError, KeyError):
-        pass
+    valu = None
+    prof = load_profile()
+    if prof and world == 1 and prof.get("headline_call", {}).get("frames_per_call") == F:
+        hc = prof["headline_call"]
+        traffic = hc["write_bytes_per_call"] + hc["fetch_bytes_per_call_corrected"]
+        valu = valu_bound(hc, kernel_us)
     out = {
         "metric": "Mrays/s (primary+shadow), 6-D hypercube @1920x1080",
         "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,20 +244,28 @@ def main():
                    "tiling": ("%d-row bands round-robin over ranks" % band_rows) if world > 1 else "single GPU",
                    "framebuffer": "resident in HBM (one buffer per frame)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "valu": valu,
                      "algorithmic_bytes_per_launch": float(own_rows) * W * fmt.bytes_per_pixel * F,
-                     "kernel": "box_kernel<6, true> (with box_cull_kernel<6> before it and box_redo_kernel<6> after it: "
-                               "one nt_render_frames_device call = these three)",
+                     "kernel": "box_tile_kernel<6, false, 16> (with box_redo_kernel<6, false, true> after it: one "
+                               "nt_render_frames_device call = these two + the camera upload kernel)",
                      "avg_launch_us": round(kernel_us, 2),
                      "algorithmic_bytes_per_ray": fmt.bytes_per_pixel,
                      "note": "BoxScene reads no scene memory: the only algorithmic HBM traffic is the packed framebuffer "
                              "(4 B/ray); the kernels are VALU- and scalar-issue bound (see DESIGN.md), so the HBM "
-                             "fraction is structurally small; avg_launch_us spans the three kernels of a call"},
+                             "fraction is structurally small -- `valu` is the bound that binds; avg_launch_us spans the kernels of a call"},
         "delivery": {"what": "RCCL gather to rank 0" if world > 1 else "D2H copy to pinned host memory",
                      "ms_per_frame": round(gather_ms, 4), "verified_equal_to_single_gpu_frame": gather_ok,
                      "value_incl_delivery": round(float(W) * H * F / ((ms_per_step + gather_ms * F) * 1e-3) / 1e6, 1)},
     }
 
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_extra = True
+    if world == 1 and not args.headline_only:
+        try:
+            out["value_rgbf32"] = value_rgbf32(torch, ntracer_amd, tracern, _lib, origins, axes, F)
+            out["scaling_proxy"] = scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_per_step)
+        except Exception as e:       # never hide the headline
+            out["scaling_proxy"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(origins, axes, W, H)
     if not args.no_extra and world == 1:
@@ -229,97 +278,166 @@ def main():
         dist.destroy_process_group()
 
 
+def _time_frames(torch, _lib, scene, fmt, origins, axes, frames, reps, opts=None, rows=None):
+    """ms per call of nt_render_frames_device (HIP events on the launch stream), framebuffers resident"""
+    fst = fmt._as_struct()
+    frame_bytes = (rows if rows is not None else fmt.height) * fmt.pitch
+    fb = torch.empty((frames, frame_bytes), dtype=torch.uint8, device="cuda")
+    o = np.ascontiguousarray(origins[:frames], np.float32)
+    a = np.ascontiguousarray(axes[:frames], np.float32)
+    st = torch.cuda.current_stream()
+
+    def go():
+        _lib.check(_lib.lib().nt_render_frames_device(scene._handle, C.c_void_p(fb.data_ptr()), frame_bytes, frames, o.ctypes.data_as(_lib.f32p),
+                                                      a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts) if opts is not None else None,
+                                                      C.c_void_p(st.cuda_stream)))
+    for _ in range(3):
+        go()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        go()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def value_rgbf32(torch, ntracer_amd, tracern, _lib, origins, axes, F):
+    """The headline workload into three fp32 channels (12 B/ray, big-endian floats: SURVEY 8d's second format): the stored
+    values are the reference's colours themselves, x / sqrtf(sq) computed as it stands."""
+    fmt = ntracer_amd.ImageFormat(1920, 1080, [ntracer_amd.Channel(*c) for c in RGBF32])
+    ms = _time_frames(torch, _lib, tracern.BoxScene(6), fmt, origins, axes, F, 10)
+    rays = 1920 * 1080 * F
+    return {"value": round(rays / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_step": round(ms, 5), "bytes_per_ray": 12,
+            "hbm_write_GBs": round(rays * 12 / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(rays * 12 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "workload": "BoxScene(6) 1920x1080, three fp32 channels, the same %d-frame sequence, one call per step" % F}
+
+
+def scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_full):
+    """What ONE rank of `--gpus 8` does per step, timed on this GPU: rank 0's bands (8 rows each, dealt round-robin to 8
+    ranks) of every frame, compact buffer.  No 8-GPU run is behind this number; it bounds the strong-scaling factor the
+    kernels allow (full step / this), before any inter-GPU effect."""
+    fmt = ntracer_amd.ImageFormat(1920, 1080, [ntracer_amd.Channel(*c) for c in RGBX8])
+    opts = _lib.NtRenderOpts()
+    opts.device = torch.cuda.current_device()
+    opts.band_rank, opts.band_world, opts.band_rows, opts.compact = 0, 8, 8, 1
+    rows = len(ntd.owned_rows(1080, 0, 8, 8))
+    ms = _time_frames(torch, _lib, tracern.BoxScene(6), fmt, origins, axes, F, 40, opts=opts, rows=rows)
+    return {"what": "rank 0 of 8: bands of 8 rows, %d of 1080 rows of each of the %d frames, on one GPU" % (rows, F),
+            "ms_per_step": round(ms, 5), "full_step_ms": round(ms_full, 5), "implied_speedup_at_8": round(ms_full / ms, 2),
+            "ideal_ms": round(ms_full / 8, 5), "measured_on": "1 GPU (no 8-GPU node was available to the builder)"}
+
+
+def cpu_quota_cores():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota if there is one"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, int(round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(origins, axes, W, H):
     """The oracle (a port of the reference's path: the same 32x32 chunk queue; hardware_concurrency()-1 worker threads
     that persist between frames and sleep on a condition variable, plus the caller -- render.cpp:769-909) on a bounded
-    sample of the same frames, all inside ONE C call (no Python between frames)."""
+    sample of the same frames, all inside ONE C call (no Python between frames).  Where a cgroup quota gives the process
+    fewer CPUs than the machine has, a second sample with that many threads is reported beside it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
-    r = ob.OracleRenderer(-1)                 # threads = cores - 1, as BlockingRenderer() does
-    sc = ob.OracleScene(6, origins[0], axes[0])
-    r.render_frames(sc, W, H, RGBX8, origins, axes, 3)          # warm-up: threads started, pages touched
-    t0 = time.perf_counter()
-    _, secs = r.render_frames(sc, W, H, RGBX8, origins, axes, 1600, max_seconds=12.0)
-    total = time.perf_counter() - t0
-    r.close()
-    frames = len(secs)
-    rate = lambda t: W * H / t / 1e6
-    return {"value": round(W * H * frames / total / 1e6, 2), "unit": "Mrays/s", "cores": r.threads, "kind": "port",
-            "best_frame_Mrays_s": round(rate(float(secs.min())), 1), "median_frame_Mrays_s": round(rate(float(np.median(secs))), 1),
-            "sample": "%d consecutive frames of the same 1920x1080 BoxScene(6) rotation in one C call, %.1f s, %d threads "
-                      "(persistent pool: %d workers + the caller)" % (frames, total, r.threads, r.threads - 1)}
+
+    def sample(threads, seconds):
+        r = ob.OracleRenderer(threads)
+        sc = ob.OracleScene(6, origins[0], axes[0])
+        r.render_frames(sc, W, H, RGBX8, origins, axes, 3)          # warm-up: threads started, pages touched
+        t0 = time.perf_counter()
+        _, secs = r.render_frames(sc, W, H, RGBX8, origins, axes, 1600, max_seconds=seconds)
+        total = time.perf_counter() - t0
+        n = r.threads
+        r.close()
+        rate = lambda t: W * H / t / 1e6
+        return {"value": round(W * H * len(secs) / total / 1e6, 2), "cores": n, "frames": len(secs), "seconds": round(total, 1),
+                "best_frame_Mrays_s": round(rate(float(secs.min())), 1), "median_frame_Mrays_s": round(rate(float(np.median(secs))), 1)}
+
+    online = os.cpu_count() or 1
+    quota = cpu_quota_cores()
+    a = sample(-1, 12.0 if quota >= online else 7.0)           # threads = hardware_concurrency() - 1 + the caller, as BlockingRenderer()
+    out = {"value": a["value"], "unit": "Mrays/s", "cores": a["cores"], "kind": "port", "best_frame_Mrays_s": a["best_frame_Mrays_s"],
+           "median_frame_Mrays_s": a["median_frame_Mrays_s"],
+           "sample": "%d consecutive frames of the same 1920x1080 BoxScene(6) rotation in one C call, %.1f s, %d threads (persistent pool: "
+                     "%d workers + the caller, the reference's default)" % (a["frames"], a["seconds"], a["cores"], a["cores"] - 1),
+           "cpus_online": online, "cpus_usable": quota}
+    if quota < online:
+        b = sample(quota - 1, 7.0)
+        b["sample"] = "the same with %d threads = the CPUs the cgroup lets this process use" % b["cores"]
+        out["at_usable_cpus"] = b
+    return out
 
 
 def extra_configs(torch, ntracer_amd, tracern, _lib):
-    """Other BASELINE.json configs, device-resident timing (not the headline)."""
+    """Other BASELINE.json configs (cfgK = configs[K]), device-resident timing (not the headline)."""
     res = {}
     G = os.path.join(ROOT, "tests", "golden")
+    prof = load_profile()
 
     def time_scene(scene, fmt, origins, axes, frames, reps, strict=False):
-        fst = fmt._as_struct()
         ropts = _lib.NtRenderOpts()
         ropts.device = -1
         ropts.band_world = 1
         ropts.strict_reference = 1 if strict else 0
-        fb = torch.empty((frames, fmt.pitch * fmt.height), dtype=torch.uint8, device="cuda")
-        o = np.ascontiguousarray(origins[:frames], np.float32)
-        a = np.ascontiguousarray(axes[:frames], np.float32)
-        st = torch.cuda.current_stream()
-
-        def go():
-            _lib.check(_lib.lib().nt_render_frames_device(scene._handle, C.c_void_p(fb.data_ptr()), fmt.pitch * fmt.height, frames,
-                                                          o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(ropts),
-                                                          C.c_void_p(st.cuda_stream)))
-        go()
-        torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            go()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps / frames       # ms per frame
+        return _time_frames(torch, _lib, scene, fmt, origins, axes, frames, reps, opts=ropts) / frames      # ms per frame
 
     chan = [ntracer_amd.Channel(*c) for c in RGBX8]
     g = np.load(os.path.join(G, "box_n3_1920x1080.npz"))
-    ms = time_scene(tracern.BoxScene(3), ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"], g["axes"], 32, 25)
-    res["config1_box3_1080p_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
-    # config 3 in the other format SURVEY 8d lists: three fp32 channels (12 B/pixel, big-endian floats)
-    g6 = np.load(os.path.join(G, "box_n6_1920x1080.npz"))
-    f32chan = [ntracer_amd.Channel(32, 1, 0, 0, 0, True), ntracer_amd.Channel(32, 0, 1, 0, 0, True), ntracer_amd.Channel(32, 0, 0, 1, 0, True)]
-    ms = time_scene(tracern.BoxScene(6), ntracer_amd.ImageFormat(1920, 1080, f32chan), g6["origins"], g6["axes"], 32, 10)
-    res["config3_box6_1080p_rgbf32_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
+    ms = time_scene(tracern.BoxScene(3), ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"], g["axes"], 160, 10)
+    res["cfg1_box3_1080p_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
     g = np.load(os.path.join(G, "box_n10_4096x4096.npz"))
     ms = time_scene(tracern.BoxScene(10), ntracer_amd.ImageFormat(4096, 4096, chan), g["origins"], g["axes"], 4, 10)
-    res["config5_box10_4096_Mrays_s"] = round(4096 * 4096 / ms / 1e3, 1)
+    res["cfg4_box10_4096_Mrays_s"] = round(4096 * 4096 / ms / 1e3, 1)
     g = np.load(os.path.join(G, "cell120_n4.npz"))
     sc = tracern.CompositeScene.from_flat(4, g)
     sel = [0, 20, 40, 60, 80, 100, 120, 140]
     ms = time_scene(sc, ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"][sel], g["axes"][sel], 8, 2)
-    res["config4_cell120_1080p_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
-    res["config4_ms_per_frame"] = round(ms, 3)
+    res["cfg3_cell120_1080p_Mrays_s"] = round(1920 * 1080 / ms / 1e3, 1)
+    res["cfg3_ms_per_frame"] = round(ms, 3)
+    if prof and "config4_call" in prof:
+        # the packet kernel's bound is instruction issue too (the scene is L2-resident: see DESIGN.md 4.2)
+        res["cfg3_valu"] = valu_bound(prof["config4_call"], ms * 1e3 * prof["config4_call"].get("frames_per_call", 8))
     # the same frames walking exactly the cells the reference walks (nt_render_opts.strict_reference; same bytes)
     ms_strict = time_scene(sc, ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"][sel], g["axes"][sel], 8, 2, strict=True)
-    res["config4_strict_reference_ms_per_frame"] = round(ms_strict, 3)
+    res["cfg3_strict_reference_ms_per_frame"] = round(ms_strict, 3)
     # SURVEY 8d byte model on the reference tree, oracle counters on frame 0: the reference's walk (32.1 branches,
     # 4.68 leaves, 195 simplices per ray) and the default walk that drops cells beyond the hit (31.2 / 4.46 / 168)
     bytes_per_ray = 16 * 32.1 + 8 * 4.68 + 195 * (4 + 4 * 21) + 4
-    res["config4_algorithmic_bytes_per_ray"] = round(bytes_per_ray)
-    res["config4_algorithmic_TB_s"] = round(bytes_per_ray * 1920 * 1080 / (ms_strict * 1e-3) / 1e12, 2)
+    res["cfg3_algorithmic_bytes_per_ray"] = round(bytes_per_ray)
+    res["cfg3_algorithmic_TB_s"] = round(bytes_per_ray * 1920 * 1080 / (ms_strict * 1e-3) / 1e12, 2)
     bytes_pruned = 16 * 31.2 + 8 * 4.46 + 168 * (4 + 4 * 21) + 4
-    res["config4_default_walk_bytes_per_ray"] = round(bytes_pruned)
-    res["config4_default_walk_TB_s"] = round(bytes_pruned * 1920 * 1080 / (ms * 1e-3) / 1e12, 2)
+    res["cfg3_default_walk_bytes_per_ray"] = round(bytes_pruned)
+    res["cfg3_default_walk_TB_s"] = round(bytes_pruned * 1920 * 1080 / (ms * 1e-3) / 1e12, 2)
     # the reference's own simplices and batches under OUR k-d tree (nt_kdtree_build): identical pixels, fewer tests
     try:
         t0 = time.perf_counter()
         reb = sc.with_rebuilt_tree()
         reb_s = time.perf_counter() - t0
         ms_reb = time_scene(reb, ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"][sel], g["axes"][sel], 8, 2)
-        res["config4_rebuilt_tree"] = {"ms_per_frame": round(ms_reb, 3), "Mrays_s": round(1920 * 1080 / ms_reb / 1e3, 1),
+        res["cfg3_rebuilt_tree"] = {"ms_per_frame": round(ms_reb, 3), "Mrays_s": round(1920 * 1080 / ms_reb / 1e3, 1),
                                        "build_s": round(reb_s, 1), "nodes": int(len(reb._flat["node_axis"]))}
     except Exception as e:
-        res["config4_rebuilt_tree"] = {"error": str(e)[:200]}
+        res["cfg3_rebuilt_tree"] = {"error": str(e)[:200]}
     # the same polytope generated and partitioned on our side (ntracer_amd.polytope + nt_kdtree_build) -- SURVEY 8d's
     # "build-tree figure"; pixels equal the reference-built scene's except on silhouettes (the reference inflates facets)
     try:
@@ -328,10 +446,10 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
         _, own, _ = polytope.build_scene(["5/2", "3", "3"])
         built_s = time.perf_counter() - t0
         ms_own = time_scene(own, ntracer_amd.ImageFormat(1920, 1080, chan), g["origins"][sel], g["axes"][sel], 8, 2)
-        res["config4_own_scene"] = {"ms_per_frame": round(ms_own, 3), "Mrays_s": round(1920 * 1080 / ms_own / 1e3, 1),
+        res["cfg3_own_scene"] = {"ms_per_frame": round(ms_own, 3), "Mrays_s": round(1920 * 1080 / ms_own / 1e3, 1),
                                     "generate_and_build_s": round(built_s, 1)}
     except Exception as e:          # the headline must not depend on the generator
-        res["config4_own_scene"] = {"error": str(e)[:200]}
+        res["cfg3_own_scene"] = {"error": str(e)[:200]}
     # the same scene with shadows on, one point light and one global light: primary + shadow rays
     n = 4
     sc.add_light(tracern.PointLight(tracern.Vector(n, (8.0, 9.0, -7.0, 3.0)), (60.0, 60.0, 60.0)))
@@ -344,7 +462,7 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
     ntracer_amd.BlockingRenderer().render(buf, fmt2, sc, collect_stats=True)
     st = sc.last_stats()
     ms2 = time_scene(sc, fmt2, g["origins"][sel], g["axes"][sel], 4, 2)
-    res["config4_shadows_960x540"] = {"primary_rays": st["rays"], "shadow_rays": st["shadow_rays"],
+    res["cfg3_shadows_960x540"] = {"primary_rays": st["rays"], "shadow_rays": st["shadow_rays"],
                                       "Mrays_s_primary_plus_shadow": round((st["rays"] + st["shadow_rays"]) / ms2 / 1e3, 1),
                                       "ms_per_frame": round(ms2, 3)}
     return res

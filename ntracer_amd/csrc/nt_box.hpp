@@ -839,7 +839,6 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
         }
         const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < R && row0 + lane < tg.row_count && ly < tg.height);
         const float v_sy = tg.fovI * ((float)ly - tg.half_h);
-        const float v_us0 = up[0] * v_sy;
         // byte offset of row rr: scalar arithmetic when the rows of the wave lie `pitch` apart in the buffer (always, unless
         // rows dealt in bands go to a full-size frame), otherwise read back from a per-lane table like sy
         const bool rows_linear = tg.band_world <= 1 || tg.compact;
@@ -903,8 +902,7 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
                 const int rr = __builtin_ctzll(quick) >> 2;
                 quick &= quick - 1ull;
                 const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
-                const float us0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_us0), rr));
-                const float d0 = base[0] - us0;                           // dir[0], bit for bit
+                const float d0 = base[0] - up[0] * sy;                    // dir[0], bit for bit
                 const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
                 const float t = (fabsf(d0) * __builtin_amdgcn_rsqf(sqa)) * maxv;
                 const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);

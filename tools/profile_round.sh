@@ -1,0 +1,39 @@
+#!/bin/bash
+# Every rocprofv3 pass behind the numbers in bench.py / DESIGN.md, on one MI355X:   tools/profile_round.sh r02
+# Writes raw output under gpurun_out/<tag>_prof/ and the summaries to commit under gpurun_out/<tag>_profiles/
+# (copy those into profiles/).  Counters are collected in passes of their own (no tracing), per MI355X_MICROARCH.md.
+tag=${1:-r02}
+root=$(pwd)
+raw=$root/gpurun_out/${tag}_prof
+out=$root/gpurun_out/${tag}_profiles
+mkdir -p $raw $out
+cd /tmp && export TMPDIR=/tmp
+B="python3 $root/bench.py --no-cpu-baseline"
+S="python3 $root/bench.py --headline-only --steps 3 --warmup 1"
+echo "[1] kernel trace of the whole bench"
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/kt -- $B > $raw/kt.log 2>&1
+cp $(ls $raw/kt/*/*_kernel_stats.csv | head -1) $out/${tag}_bench_kernel_stats.csv
+grep "^{" $raw/kt.log > $out/${tag}_bench_under_profiler.json
+echo "[2] HBM bytes: WRITE_SIZE and FETCH_SIZE, separate passes"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $raw/w -- $S > $raw/w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $raw/f -- $S > $raw/f.log 2>&1
+echo "[3] SQ counters of the headline kernels"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $raw/sq -- $S > $raw/sq.log 2>&1
+echo "[3b] the fp32x3 format of the same workload: SQ counters and bytes"
+F32="python3 $root/tools/band_proxy.py --world 1 --f32 --frames 160 --steps 3 --warmup 1"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $raw/f32sq -- $F32 > $raw/f32sq.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $raw/f32w -- $F32 > $raw/f32w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $raw/f32f -- $F32 > $raw/f32f.log 2>&1
+echo "[4] config 4 (120-cell, composite_packet): SQ counters, then bytes"
+C4="python3 $root/tools/run_composite.py cell120_n4 8"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $raw/c4sq -- $C4 > $raw/c4sq.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $raw/c4w -- $C4 > $raw/c4w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $raw/c4f -- $C4 > $raw/c4f.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/c4kt -- $C4 > $raw/c4kt.log 2>&1
+cp $(ls $raw/c4kt/*/*_kernel_stats.csv | head -1) $out/${tag}_config4_kernel_stats.csv
+echo "[5] the one-eighth band of the headline workload (what a rank of an 8-GPU run does)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/b8 -- python3 $root/tools/band_proxy.py --world 8 > $raw/b8.log 2>&1
+cp $(ls $raw/b8/*/*_kernel_stats.csv | head -1) $out/${tag}_band8_kernel_stats.csv
+cd $root
+python3 tools/pmc_summary.py $raw $out $tag
+ls -la $out
