@@ -121,6 +121,246 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
 }
 
 // --------------------------------------------------------------------------------------
+// BoxScene, run-time n, packed plain RGB (RGBX8 & co.): the structure of box_tile_kernel (nt_box.hpp) with the n-vectors in
+// LDS.  A block = 64 columns x 32 rows (four waves of eight rows); one wave works out the stretch codes of the tile
+// (box_stretch_code_var: what box_stretch_code computes, with loops over n); then every lane builds forward + right*sx
+// once (base[j], in LDS as [j][thread]) together with the three dot products that give |dir|^2 as a quadratic in sy, and
+//   * rows the codes call background or one face throughout cost a handful of operations per pixel WHATEVER n is
+//     (guarded rsq quantisation as in box_tile_kernel),
+//   * the others are evaluated ray by ray like box_kernel_var does (the reference's arithmetic on the faces in a near-tie).
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t box_stretch_code_var(int n, const float *camrow, const NtTarget &tg, int y, int col) {
+    const float *org = camrow, *right = camrow + n, *up = camrow + 2 * n, *fwd = camrow + 3 * n;
+    float omax = fabsf(org[0]);
+    for (int j = 1; j < n; ++j) omax = fmaxf(omax, fabsf(org[j]));
+    const float m = NT_BOX_MARGIN * (1.0f + omax);
+    const float h = 1.0f + 2.0f * m + 1e-3f;
+    const float sxc = tg.fovI * (((float)(col * 64) + 31.5f) - tg.half_w);
+    const float sy = tg.fovI * ((float)y - tg.half_h);
+    const float spread = 32.0f * tg.fovI;
+    float tlo = 0.0f, thi = INFINITY;
+    bool dead = false;
+    float tn = -INFINITY, tn2 = -INFINITY, vK = 0.0f, gK = 0.0f, oK = 0.0f;
+    int K = 0;
+    for (int j = 0; j < n; ++j) {
+        const float vc = (fwd[j] + right[j] * sxc) - up[j] * sy;
+        const float g = fmaf(spread, fabsf(right[j]), 1e-6f);
+        const float pa = vc + g, qa = -h - org[j];
+        const float pb = vc - g, qb = h - org[j];
+        const float ra = qa * __builtin_amdgcn_rcpf(pa), rb = qb * __builtin_amdgcn_rcpf(pb);
+        const float lo_a = pa > 0.0f ? ra : -INFINITY, hi_a = pa < 0.0f ? ra : INFINITY;
+        const float hi_b = pb > 0.0f ? rb : INFINITY, lo_b = pb < 0.0f ? rb : -INFINITY;
+        tlo = fmaxf(tlo, fmaxf(lo_a, lo_b));
+        thi = fminf(thi, fminf(hi_a, hi_b));
+        dead = dead || (pa == 0.0f && qa > 0.0f) || (pb == 0.0f && qb < 0.0f);
+        const float nr = ((vc < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc);
+        tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);
+        const bool later = nr > tn;
+        vK = later ? vc : vK;
+        gK = later ? g : gK;
+        oK = later ? org[j] : oK;
+        K = later ? j : K;
+        tn = fmaxf(tn, nr);
+    }
+    if (dead || tlo > thi) return 0u;                  // a NaN keeps the stretch
+    uint32_t code = 15u;
+    const float vKa = vK - gK, vKb = vK + gK;
+    if (K <= 12 && vKa * vKb > 0.0f) {                 // (codes 1 .. 13 name the face)
+        const float num = (vK < 0.0f ? 1.0f : -1.0f) - oK;
+        const float t1 = num * __builtin_amdgcn_rcpf(vKa), t2 = num * __builtin_amdgcn_rcpf(vKb);
+        const float t_lo = fminf(t1, t2) * (1.0f - 1e-6f), t_hi = fmaxf(t1, t2) * (1.0f + 1e-6f);
+        const float rK = m * __builtin_amdgcn_rcpf(fminf(fabsf(vKa), fabsf(vKb))) * (1.0f + 1e-6f);
+        bool ok = t_lo > 1e-3f && t_hi < 1e30f;
+        for (int j = 0; j < n; ++j) {
+            const float vc = (fwd[j] + right[j] * sxc) - up[j] * sy;
+            const float g = fmaf(spread, fabsf(right[j]), 1e-6f);
+            const float va = vc - g, vb = vc + g;
+            const float pmax = org[j] + fmaxf(vb * t_lo, vb * t_hi);
+            const float pmin = org[j] + fminf(va * t_lo, va * t_hi);
+            const float lim = (1.0f - m - 1e-4f) - fmaxf(fabsf(va), fabsf(vb)) * rK;
+            ok = ok && (j == K || (pmax <= lim && pmin >= -lim));
+        }
+        if (ok) code = (uint32_t)K + 1u;
+    }
+    return code;
+}
+
+__global__ __launch_bounds__(256) void box_rows_kernel_var(NtCamera cam, NtTarget tg) {
+    constexpr int R = 8;
+    extern __shared__ float lds_var[];   // base [n][256], dirs [n][256], camera rows [4][n], codes [4]
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = cam.n;
+    float *base = lds_var + tid, *dirs = lds_var + (size_t)n * 256 + tid;          // component j at [j * 256]
+    float *camrow = lds_var + (size_t)2 * n * 256;
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(camrow + 4 * n);
+    {
+        const float *src = cam.buf ? cam.buf + (size_t)blockIdx.z * 4 * n : nullptr;
+        for (int k = tid; k < 4 * n; k += 256) camrow[k] = src ? src[k] : cam.inl[k];
+    }
+    __syncthreads();
+    const float *org = camrow, *right = camrow + n, *up = camrow + 2 * n, *fwd = camrow + 3 * n;
+    const int tile_row0 = (int)blockIdx.y * 4 * R;
+    if (wv == (int)((blockIdx.x + blockIdx.y + blockIdx.z) & 3u)) {
+        uint32_t code = 0u;
+        const int trow = tile_row0 + lane;
+        if (lane < 4 * R && trow < tg.row_count) {
+            const int orow = tg.row_begin + trow;
+            int y = orow;
+            if (tg.band_world > 1) {
+                const int band = orow / tg.band_rows;
+                y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
+            }
+            if (y < tg.height) code = box_stretch_code_var(n, camrow, tg, y, (int)blockIdx.x);
+        }
+        uint32_t packed = code << (4 * (lane & 7));
+        packed |= (uint32_t)__shfl_xor((int)packed, 1, 64);
+        packed |= (uint32_t)__shfl_xor((int)packed, 2, 64);
+        packed |= (uint32_t)__shfl_xor((int)packed, 4, 64);
+        if ((lane & 7) == 0 && lane < 4 * R) s_code[lane >> 3] = packed;          // wave w's eight rows: s_code[w]
+    }
+    __syncthreads();
+    const int row0 = tile_row0 + wv * R;
+    if (row0 >= tg.row_count) return;
+    const uint32_t rowcodes = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[wv]);
+    // row bookkeeping: one row per lane, read back with v_readlane (see box_tile_kernel)
+    const int lorow = tg.row_begin + row0 + lane;
+    int ly = lorow;
+    if (tg.band_world > 1) {
+        const int band = lorow / tg.band_rows;
+        ly = (band * tg.band_world + tg.band_rank) * tg.band_rows + (lorow - band * tg.band_rows);
+    }
+    const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < R && row0 + lane < tg.row_count && ly < tg.height);
+    const float v_sy = tg.fovI * ((float)ly - tg.half_h);
+    const long long v_off = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? lorow : ly) * tg.pitch;
+    const int v_off_lo = (int)v_off, v_off_hi = (int)(v_off >> 32);
+    int x = (int)blockIdx.x * 64 + lane;
+    x = x < tg.width ? x : tg.width - 1;                 // lanes past the right edge redo the last pixel
+    const long long xoff = (long long)x * tg.bpp;
+    const float sx = tg.fovI * ((float)x - tg.half_w);
+    float bb = 0.0f, bu = 0.0f, uu = 0.0f;
+    for (int j = 0; j < n; ++j) {
+        const float b = fwd[j] + right[j] * sx;
+        base[j * 256] = b;
+        bb = fmaf(b, b, bb);
+        bu = fmaf(b, up[j], bu);
+        uu = fmaf(up[j], up[j], uu);
+    }
+    const float base0 = base[0], up0 = up[0];
+    const float m2bu = -2.0f * bu;
+    // (the quadratic's error grows with n: (3.7n + 4) * 2^-24 relative -- the guard below is sized for it)
+    const bool fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
+    const float guard = (5.55f * (float)n + 21.0f) * 0x1p-24f;         // three times the error bound (1.85n + 7) * 2^-24 of t: 2^-18 at n = 8
+    const float maxv = (float)tg.plain_maxval;
+    float dots[4];
+    if (cam.buf) {
+        const float *dp = cam.buf + (size_t)gridDim.z * 4 * n + (size_t)blockIdx.z * 4;
+        dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
+    } else {
+        dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
+    }
+    for (int rr = 0; rr < R; ++rr) {
+        if (!((valid >> rr) & 1u)) continue;
+        const uint32_t code = (rowcodes >> (4 * rr)) & 15u;
+        const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+        PixelRef pr;
+        pr.x = x;
+        pr.y = 0;
+        pr.offset = (((long long)__builtin_amdgcn_readlane(v_off_hi, rr) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, rr)) + xoff;
+        pr.hit_index = 0;
+        pr.valid = true;
+        if (fastsq && code <= 13u) {
+            // background (code 0) or face K = code - 1 throughout: |x| / |dir| from x = dir[0] or dir[K] alone
+            const int K = code == 0u ? 0 : (int)code - 1;
+            const float xk = (code == 0u ? base0 : base[K * 256]) - (code == 0u ? up0 : up[K]) * sy;       // dir[K], bit for bit
+            const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
+            const float t = (fabsf(xk) * __builtin_amdgcn_rsqf(sqa)) * maxv, th = t * 0.5f;
+            const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, guard, guard) &&
+                               (code == 0u || fabsf(__builtin_amdgcn_fractf(th) - 0.5f) > fmaf(th, guard, guard));
+            if (__builtin_amdgcn_ballot_w64(!clear) == 0ull) {
+                uint32_t q = (uint32_t)(t + 0.5f), qh = (uint32_t)(th + 0.5f);
+                q = q < tg.plain_maxval ? q : tg.plain_maxval;
+                qh = qh < tg.plain_maxval ? qh : tg.plain_maxval;
+                if (code == 0u) emit_plain(tg, pr, xk > 0.0f ? q : 0u, q);
+                else emit_plain(tg, pr, q, qh);
+                continue;
+            }
+        }
+        // ---- ray by ray: box_kernel_var's evaluation (the reference's arithmetic on the faces in a near-tie with the
+        // last-reached one), with the direction in `dirs`
+        float sq = 0.0f;
+        for (int j = 0; j < n; ++j) {
+            const float v = base[j * 256] - up[j] * sy;
+            dirs[j * 256] = v;
+            sq = j == 0 ? v * v : sq + v * v;
+        }
+        const float len = sqrtf(sq);
+        const float osq = dots[0];
+        const float ov = fmaf(-dots[2], sy, fmaf(dots[1], sx, dots[3]));
+        const float rad2 = (float)n * (1.0f + NT_FUZZ) * (1.0f + NT_FUZZ) * 1.001f;
+        const bool maybe = code != 0u && !((osq - rad2 * 1.0001f - 1e-5f * osq) * sq > ov * ov * 1.0001f);
+        const bool wave_maybe = __builtin_amdgcn_ballot_w64(maybe) != 0ull;
+        bool done = false;
+        float shade = 0.0f;
+        if (wave_maybe) {
+            for (int j = 0; j < n; ++j) dirs[j * 256] = dirs[j * 256] / len;
+            float aK = 0.0f, bK = 1.0f, oK = 0.0f;
+            bool any = false;
+            for (int i = 0; i < n; ++i) {
+                const float di = dirs[i * 256];
+                const float oi = org[i];
+                const float num = (di < 0.0f ? 1.0f : -1.0f) - oi;
+                const bool pre = maybe && ((num > 0.0f && di > 0.0f) || (num < 0.0f && di < 0.0f));
+                const float a = fabsf(num), bq = fabsf(di);
+                if (pre && (!any || a * bK > aK * bq)) { aK = a; bK = bq; oK = oi; any = true; }
+            }
+            const float mu = 1e-4f * (1.0f + fabsf(oK));
+            const float aKm = (aK - mu) * (1.0f - 1e-6f);
+            for (int i = 0; i < n; ++i) {
+                const float di = dirs[i * 256];
+                const float oi = org[i];
+                const float s_ = di < 0.0f ? 1.0f : -1.0f;
+                const float num = s_ - oi;
+                const bool pre = maybe && ((num > 0.0f && di > 0.0f) || (num < 0.0f && di < 0.0f));
+                const bool tie = pre && !done && !(fabsf(num) * bK < fabsf(di) * aKm);
+                if (__builtin_amdgcn_ballot_w64(tie) == 0ull) continue;
+                const float dist = num / di;
+                bool ok = tie && dist > 0.0f;
+                for (int j = 0; j < n; ++j) {
+                    if (j != i) {
+                        const float pj = dirs[j * 256] * dist + org[j];
+                        ok = ok && !(fabsf(pj) > (1.0f + NT_FUZZ));
+                    }
+                }
+                if (ok) {
+                    done = true;
+                    if (dist >= FLT_MAX) shade = -1.0f;
+                    else {
+                        const float sine = di * s_;
+                        shade = sine <= 0.0f ? -sine : 0.0f;
+                    }
+                }
+            }
+        } else {
+            dirs[0] = dirs[0] / len;
+        }
+        float r, g, b;
+        if (done && shade >= 0.0f) {
+            r = shade * 1.0f;
+            g = shade * 0.5f;
+            b = shade * 0.5f;
+        } else {
+            const float in = dirs[0];
+            if (in > 0.0f) { r = in; g = in; b = in; }
+            else { r = 0.0f; g = -in; b = -in; }
+        }
+        (void)b;
+        emit_plain(tg, pr, plain_quantize(tg, r), plain_quantize(tg, g));            // g == b
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // CompositeScene, run-time n (up to 64): the reference's generic `tracern` module (var_geometry.hpp).  Per-lane
 // kernel, the whole of composite_scene::calculate_color for opaque scenes: batches, unbatched triangles, Solids,
 // point / global / camera lights, shadow rays (with _occludes' far-child rule), reflection.  The current ray's n-vectors
@@ -705,6 +945,17 @@ int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &t
         case 9: nt_box_fixed_9(li, cam, tg); break;
         case 10: nt_box_fixed_10(li, cam, tg); break;
         default: {
+            // packed plain RGB of <= 10 bits in one aligned dword: the rows kernel (codes + lean loops), if its n-vectors fit LDS
+            const size_t lds_rows = ((size_t)2 * li.n * 256 + (size_t)4 * li.n + 4) * sizeof(float);
+            const char *er = getenv("NTRACER_BOX_VAR_ROWS");
+            if (!tg.colors_out && tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4 && lds_rows <= 160 * 1024 &&
+                !(er && atoi(er) == 0)) {
+                const dim3 grid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + 31) / 32), (unsigned)li.nframes);
+                if (lds_rows > 64 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(box_rows_kernel_var), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+                hipLaunchKernelGGL(box_rows_kernel_var, grid, dim3(256), lds_rows, (hipStream_t)li.stream, cam, tg);
+                break;
+            }
             dim3 grid;
             grid_for(tg, 64, 4, li.nframes, grid);
             const size_t lds = ((size_t)li.n * 256 + (size_t)4 * li.n) * sizeof(float);

@@ -118,7 +118,7 @@ def _stress_cameras(n, rng):
     return cams
 
 
-@pytest.mark.parametrize("n", [3, 4, 6, 8, 10])
+@pytest.mark.parametrize("n", [3, 4, 6, 8, 10, 11, 13, 20])
 def test_box_stress_cameras_bytes_and_floats_equal_oracle(n):
     """The BoxScene kernel sorts rays into clear misses, clear hits and unclear ones, and only the last get the
     reference-ordered evaluation; quantised formats also skip the sqrt and the division away from rounding
@@ -164,6 +164,37 @@ def test_box_byte_orders_of_packed_rgb(rev):
         img = render_host(sc, fmt_of(w, h, chans, 0, rev))
         ref = ob.OracleScene(6, g["origins"][f], g["axes"][f]).render(w, h, chans, reversed_=rev, threads=7)
         assert np.array_equal(img, ref), (k, rev, int((img != ref).sum()))
+
+
+def test_run_time_n_rows_kernel_on_the_bench_frames(monkeypatch):
+    """NTRACER_FORCE_VAR=1 sends BoxScene(6) through box_rows_kernel_var (stretch codes and lean loops with run-time n): a
+    multi-frame launch of bench cameras at 1920x1080 and a 10-D frame at 4096 columns, byte for byte against the frames
+    of the compile-time-N kernels (which other tests pin to the oracle); and the plain per-pixel kernel
+    (NTRACER_BOX_VAR_ROWS=0) gives the same."""
+    import torch
+    g = fx.load("box_n6_1920x1080")
+    w, h = 1920, 1080
+    fmt = fmt_of(w, h, fx.RGBX8)
+    frames = [0, 17, 40, 77, 93, 120, 141, 159]
+    o = np.ascontiguousarray(g["origins"][frames], np.float32)
+    a = np.ascontiguousarray(g["axes"][frames], np.float32)
+    st_ = fmt._as_struct()
+
+    def launch():
+        sc = tracern.BoxScene(6)
+        fb = torch.zeros((len(frames), h * fmt.pitch), dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), h * fmt.pitch, len(frames), o.ctypes.data_as(_lib.f32p),
+                                                      a.ctypes.data_as(_lib.f32p), C.byref(st_), None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        return fb.cpu().numpy()
+
+    fixed = launch()
+    monkeypatch.setenv("NTRACER_FORCE_VAR", "1")
+    rows = launch()
+    assert np.array_equal(rows, fixed), int((rows != fixed).sum())
+    monkeypatch.setenv("NTRACER_BOX_VAR_ROWS", "0")
+    plain = launch()
+    assert np.array_equal(plain, fixed)
 
 
 def test_box_wide_rows_and_the_kernel_without_stretch_codes(monkeypatch):
@@ -751,6 +782,48 @@ def test_bench_workload_every_frame_equals_the_oracle():
         osc.set_camera(o[f], a[f])
         ref = osc.render(w, h, fx.RGBX8, threads=threads)
         assert np.array_equal(got[f], ref), f
+
+
+def test_bench_workload_in_bands_and_in_float_channels():
+    """The large-launch tile shape (sixteen rows a lane) in the two other guises the bench uses: (1) one rank's bands of an
+    8-GPU run -- rows dealt in bands of 8, compact buffer -- must be the corresponding rows of the whole frames (which
+    test_bench_workload_every_frame_equals_the_oracle pins to the oracle); (2) three fp32 channels: whole frames byte for
+    byte against the oracle."""
+    import os
+    import torch
+    g = fx.load("box_n6_1920x1080")
+    w, h = 1920, 1080
+    sc = tracern.BoxScene(6)
+    o = np.ascontiguousarray(g["origins"], np.float32)
+    a = np.ascontiguousarray(g["axes"], np.float32)
+    nf = len(o)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def launch(fmt, frames, opts, rows):
+        fb = torch.zeros((len(frames), rows * fmt.pitch), dtype=torch.uint8, device="cuda")
+        st_ = fmt._as_struct()
+        of, af = np.ascontiguousarray(o[frames]), np.ascontiguousarray(a[frames])
+        _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), rows * fmt.pitch, len(frames), of.ctypes.data_as(_lib.f32p),
+                                                      af.ctypes.data_as(_lib.f32p), C.byref(st_), C.byref(opts) if opts is not None else None, stream))
+        torch.cuda.synchronize()
+        return fb.cpu().numpy().reshape(len(frames), rows, fmt.pitch)
+
+    fmt = fmt_of(w, h, fx.RGBX8)
+    whole = launch(fmt, list(range(nf)), None, h)
+    for rank in (0, 5):
+        opts = _lib.NtRenderOpts()
+        opts.device, opts.band_rank, opts.band_world, opts.band_rows, opts.compact = 0, rank, 8, 8, 1
+        rows = ntd.owned_rows(h, rank, 8, 8)
+        part = launch(fmt, list(range(nf)), opts, len(rows))
+        assert np.array_equal(part, whole[:, rows, :]), rank
+    frames = list(range(0, nf, 4))                        # 40 frames: still the large-launch shape
+    fmt32 = fmt_of(w, h, fx.RGBF32)
+    got = launch(fmt32, frames, None, h)
+    threads = max(1, min(63, (os.cpu_count() or 2) - 1))
+    osc = ob.OracleScene(6, o[0], a[0])
+    for k in (0, 7, 23) if threads < 16 else range(0, len(frames), 3):
+        osc.set_camera(o[frames[k]], a[frames[k]])
+        assert np.array_equal(got[k], osc.render(w, h, fx.RGBF32, threads=threads)), frames[k]
 
 
 @pytest.mark.parametrize("frame", [0, 40, 93])
