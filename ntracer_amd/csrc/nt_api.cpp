@@ -432,8 +432,6 @@ int check_renderable(const nt_scene *s) {
         if (!s->all_opaque && s->any_reflective && s->max_reflect_depth > 5)
             return fail(NT_E_UNSUPPORTED, "max_reflect_depth > 5 is not supported for scenes with transparent materials");
         if (s->nodes.size() >= (1u << 24)) return fail(NT_E_UNSUPPORTED, "k-d trees with 2^24 or more nodes are not supported");
-        if (s->max_reflect_depth > NT_DEV_MAX_REFLECT && s->any_reflective)
-            return fail(NT_E_UNSUPPORTED, "max_reflect_depth > %d is not supported", NT_DEV_MAX_REFLECT);
     }
     return NT_OK;
 }

@@ -677,6 +677,7 @@ template <int N, bool FEAT, bool STATS>
 __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, const WaveLds &w, int lane, float (&o)[N], float (&d)[N], Stats &st,
                                                   const Hit *primary = nullptr) {
     Level levels[FEAT ? NT_DEV_MAX_REFLECT : 1];
+    Color3 deep_a = c3(0.0f, 0.0f, 0.0f), deep_b = c3(1.0f, 1.0f, 1.0f);      // levels beyond the stack: colour = deep_a + deep_b * (next)
     int depth = 0;
     int skip_item = -1, skip_lane = -1;
     Color3 result;
@@ -770,13 +771,24 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
         }
         const Color3 r0 = cadd(c3p(sc.ambient), cmul(c3p(m), light));
 
-        if (FEAT && m[7] != 0.0f && depth < sc.max_reflect_depth && depth < NT_DEV_MAX_REFLECT) {
-            Level &L = levels[depth];
-            L.spec = specular;
-            L.spec_a = spec_a;
-            L.r0 = r0;
-            L.c = c3p(m);
-            L.refl = m[7];
+        if (FEAT && m[7] != 0.0f && depth < sc.max_reflect_depth) {
+            if (depth < NT_DEV_MAX_REFLECT) {
+                Level &L = levels[depth];
+                L.spec = specular;
+                L.spec_a = spec_a;
+                L.r0 = r0;
+                L.c = c3p(m);
+                L.refl = m[7];
+            } else {
+                // deeper than the level stack: this level's colour is alpha + beta * (colour of the reflected ray); fold it
+                // into the running pair for everything below the stack (same terms as the unwinding loop, associated
+                // differently: the contribution is damped by sixteen reflectivities by now)
+                const float k1 = 1.0f - spec_a;
+                const Color3 alpha = cadd(specular, cscale(cscale(r0, 1.0f - m[7]), k1));
+                const Color3 beta = cscale(cscale(c3p(m), m[7]), k1);
+                deep_a = cadd(deep_a, cmul(deep_b, alpha));
+                deep_b = cmul(deep_b, beta);
+            }
             const float f = -2.0f * sine;
 #pragma unroll
             for (int k = 0; k < N; ++k) { d[k] = d[k] - nd[k] * f; o[k] = no[k]; }
@@ -789,6 +801,10 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
         break;
     }
     if (FEAT) {
+        if (depth > NT_DEV_MAX_REFLECT) {
+            result = cadd(deep_a, cmul(deep_b, result));
+            depth = NT_DEV_MAX_REFLECT;
+        }
         while (depth > 0) {
             --depth;
             const Level &L = levels[depth];

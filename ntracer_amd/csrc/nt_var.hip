@@ -742,6 +742,7 @@ __device__ __noinline__ Color3 composite_color_var(const VarCtx &cx) {
     const NtCompositeDev &sc = cx.sc;
     const int n = cx.n;
     Level levels[NT_DEV_MAX_REFLECT];
+    Color3 deep_a = c3(0.0f, 0.0f, 0.0f), deep_b = c3(1.0f, 1.0f, 1.0f);
     int depth = 0;
     int skip_item = -1, skip_lane = -1;
     Color3 result;
@@ -836,13 +837,21 @@ __device__ __noinline__ Color3 composite_color_var(const VarCtx &cx) {
             }
         }
         const Color3 r0 = cadd(c3p(sc.ambient), cmul(c3p(m), light));
-        if (m[7] != 0.0f && depth < sc.max_reflect_depth && depth < NT_DEV_MAX_REFLECT) {
-            Level &Lv = levels[depth];
-            Lv.spec = specular;
-            Lv.spec_a = spec_a;
-            Lv.r0 = r0;
-            Lv.c = c3p(m);
-            Lv.refl = m[7];
+        if (m[7] != 0.0f && depth < sc.max_reflect_depth) {
+            if (depth < NT_DEV_MAX_REFLECT) {
+                Level &Lv = levels[depth];
+                Lv.spec = specular;
+                Lv.spec_a = spec_a;
+                Lv.r0 = r0;
+                Lv.c = c3p(m);
+                Lv.refl = m[7];
+            } else {                        // beyond the level stack: folded into a running affine pair (see composite_color)
+                const float k1 = 1.0f - spec_a;
+                const Color3 alpha = cadd(specular, cscale(cscale(r0, 1.0f - m[7]), k1));
+                const Color3 beta = cscale(cscale(c3p(m), m[7]), k1);
+                deep_a = cadd(deep_a, cmul(deep_b, alpha));
+                deep_b = cmul(deep_b, beta);
+            }
             const float f = -2.0f * sine;
             for (int k = 0; k < n; ++k) dir[k] = dir[k] - nd[k] * f;
             var_set_ray(cx, no, dir);
@@ -853,6 +862,10 @@ __device__ __noinline__ Color3 composite_color_var(const VarCtx &cx) {
         }
         result = cadd(specular, cscale(r0, 1.0f - spec_a));
         break;
+    }
+    if (depth > NT_DEV_MAX_REFLECT) {
+        result = cadd(deep_a, cmul(deep_b, result));
+        depth = NT_DEV_MAX_REFLECT;
     }
     while (depth > 0) {
         --depth;

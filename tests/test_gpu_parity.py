@@ -990,6 +990,51 @@ def test_transparency_vs_oracle(monkeypatch):
         assert np.abs(c - o).max() < TOL_ORACLE, str(v)
 
 
+def test_reflection_deeper_than_the_level_stack(monkeypatch):
+    """Two mirrors facing each other (reflectivity 0.9) and a camera between them: rays bounce until max_reflect_depth,
+    here 40 -- the reference recurses to any depth (tracer.hpp:1842-1851); the kernels keep 16 levels exactly nested and
+    fold deeper ones into a running affine pair.  Against the oracle's plain recursion, in three dimensions (compile-time-N
+    kernels) and through the run-time-n kernel."""
+    from ntracer_amd import NTracer
+    nt = NTracer(3)
+    mirror = ntracer_amd.Material((0.95, 0.9, 0.85), 1, 0.9, 0.4, 20)
+    red = ntracer_amd.Material((1, 0.3, 0.2), 1, 0.0)
+    V = nt.Vector
+    protos = []
+    for z, flip in ((1.5, False), (-1.5, True)):
+        quad = [(-300, -300, z), (300, -300, z), (300, 300, z), (-300, 300, z)]
+        if flip:
+            quad = quad[::-1]
+        protos.append(nt.TrianglePrototype([V(*quad[0]), V(*quad[1]), V(*quad[2])], mirror))
+        protos.append(nt.TrianglePrototype([V(*quad[0]), V(*quad[2]), V(*quad[3])], mirror))
+    protos.append(nt.TrianglePrototype([V(-0.4, -0.3, 0.9), V(0.5, -0.3, 0.6), V(0.1, 0.5, 0.8)], red))
+    sc = nt.build_composite_scene(protos)
+    flat = sc._flat_description()
+    flat["batch_size"] = 4
+    origin = np.array([0.3, 0.2, 0.0], np.float32)
+    axes = np.eye(3, dtype=np.float32)
+    axes[0] = (0.995, 0.0, 0.0998)
+    axes[2] = (-0.0998, 0.0, 0.995)
+    params = dict(fov=0.9, shadows=0, camera_light=1, max_reflect_depth=40, bg_gradient_axis=1, ambient=[.05, .05, .05], bg1=[1, 1, 1],
+                  bg2=[0, 0, 0], bg3=[0, 1, 1], point_light_pos=np.zeros((0, 3)), point_light_color=np.zeros((0, 3)),
+                  global_light_dir=[[0.1, -1.0, 0.2]], global_light_color=[[0.3, 0.3, 0.3]])
+    w, h = 96, 64
+    ys, xs = np.mgrid[0:h, 0:w]
+    osc = ob.OracleScene(3, origin, axes, flat=flat, params=params)
+    o, cnt = osc.colors_at(xs.ravel(), ys.ravel(), w, h, counters=True)
+    assert cnt["rays"] > 20 * w * h                       # most rays really go tens of levels deep
+    for force_var in (False, True):
+        if force_var:
+            monkeypatch.setenv("NTRACER_FORCE_VAR", "1")
+        sc2 = tracern.CompositeScene.from_flat(3, flat)
+        sc2.set_params_flat(params)
+        sc2._set_camera_arrays(origin, axes)
+        c = sc2.colors_at(xs.ravel(), ys.ravel(), w, h)
+        assert np.abs(c - o).max() < TOL_ORACLE, force_var
+        img = render_host(sc2, fmt_of(w, h, fx.RGBF32)).view(">f4").reshape(h, w, 3)
+        assert np.abs(img - np.clip(o, 0, 1).reshape(h, w, 3)).max() < TOL_ORACLE, force_var
+
+
 def test_shadow_rays_are_counted():
     g = fx.load("feature3d")
     flat = fx.flat_of(g, opaque=True)
