@@ -52,7 +52,26 @@ def _flag_tag():
     return hashlib.sha1(" ".join(FLAGS + EXTRA).encode()).hexdigest()[:8]
 
 
+PYBUF_SRC = os.path.join(CSRC, "nt_pybuffer.c")
+PYBUF_OUT = os.path.join(HERE, "_pybuffer.so")
+
+
+def build_pybuffer(force=False, verbose=False):
+    """the one-type CPython module that gives Vector / Color the buffer protocol (host convenience; plain gcc)"""
+    if not force and not _stale(PYBUF_OUT, [PYBUF_SRC]):
+        return PYBUF_OUT
+    import sysconfig
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-I" + sysconfig.get_paths()["include"], PYBUF_SRC, "-o", PYBUF_OUT + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(PYBUF_OUT + ".tmp", PYBUF_OUT)
+    return PYBUF_OUT
+
+
 def build(force=False, verbose=False, out=None):
+    if out is None:
+        build_pybuffer(force, verbose)
     out = out or OUT
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()

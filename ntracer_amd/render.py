@@ -21,6 +21,19 @@ MAX_PIXELSIZE = 16        # render.cpp:50
 DEFAULT_SPECULAR_EXP = 8  # render.cpp:44
 
 
+def _float_buffer_base():
+    """`FloatBuffer` of the one-type CPython module built beside libntracer_hip.so (csrc/nt_pybuffer.c): the buffer protocol
+    for Color and Vector, as the reference's types have it.  Without the module they are plain objects."""
+    try:
+        from . import _pybuffer
+        return _pybuffer.FloatBuffer
+    except ImportError:
+        return object
+
+
+FloatBuffer = _float_buffer_base()
+
+
 class Channel(object):
     """render.Channel(bit_size,f_r,f_g,f_b[,f_c=0,tfloat=False]) -- render.cpp:95-164."""
     __slots__ = ("_v",)
@@ -103,9 +116,15 @@ class ImageFormat(object):
         return f
 
 
-class Color(object):
-    """render.Color(r,g,b) -- light.hpp:4-110, render.cpp:969-1152."""
+class Color(FloatBuffer):
+    """render.Color(r,g,b) -- light.hpp:4-110, render.cpp:969-1152.  memoryview(c) gives its three floats."""
     __slots__ = ("r", "g", "b")
+
+    def _float_buffer(self):
+        import numpy as np
+        a = np.array((self.r, self.g, self.b), np.float32)
+        a.flags.writeable = False
+        return a
 
     def __init__(self, r, g, b):
         object.__setattr__(self, "r", C.c_float(r).value)

@@ -32,9 +32,14 @@ def _vec(n, values):
     return a
 
 
-class Vector(object):
-    """tracern.Vector(dimension[,values]) -- fp32 n-vector (geometry.hpp:131-283)."""
+class Vector(_render.FloatBuffer):
+    """tracern.Vector(dimension[,values]) -- fp32 n-vector (geometry.hpp:131-283).  memoryview(v) gives its floats."""
     __slots__ = ("_v",)
+
+    def _float_buffer(self):
+        a = self._v.view()
+        a.flags.writeable = False
+        return a
 
     def __init__(self, dimension, values=None):
         dimension = int(dimension)
@@ -44,7 +49,7 @@ class Vector(object):
 
     @classmethod
     def _wrap(cls, a):
-        v = object.__new__(cls)
+        v = cls.__new__(cls)
         v._v = np.ascontiguousarray(a, dtype=f32)
         return v
 

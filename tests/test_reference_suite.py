@@ -164,6 +164,19 @@ def test_prototype_from_triangle_and_from_batch():
             almost(tbp.point_data[j].point[i], tris[i][0][j], 3)
 
 
+def test_buffer_interface():
+    """lib/ntracer/tests/test.py:294-300: Vector and Color expose their floats through the buffer protocol."""
+    nt = NTracer(7)
+    v = nt.Vector(1, 2, 3, 4, 5, 6, 7)
+    assert list(v) == list(memoryview(v))
+    mv = memoryview(v)
+    assert mv.format == "f" and mv.readonly and mv.nbytes == 28
+    c = ntracer_amd.Color(0.5, 0.1, 0)
+    assert list(c) == list(memoryview(c))
+    with pytest.raises((TypeError, ValueError, BufferError)):
+        memoryview(v)[0] = 2.0
+
+
 def test_pickle_round_trips_with_equality():
     """test_pickle, :368-385"""
     rnd = random.Random(5)
