@@ -375,16 +375,25 @@ def cpu_baseline(origins, axes, W, H):
 
     online = os.cpu_count() or 1
     quota = cpu_quota_cores()
-    a = sample(-1, 12.0 if quota >= online else 7.0)           # threads = hardware_concurrency() - 1 + the caller, as BlockingRenderer()
-    out = {"value": a["value"], "unit": "Mrays/s", "cores": a["cores"], "kind": "port", "best_frame_Mrays_s": a["best_frame_Mrays_s"],
-           "median_frame_Mrays_s": a["median_frame_Mrays_s"],
-           "sample": "%d consecutive frames of the same 1920x1080 BoxScene(6) rotation in one C call, %.1f s, %d threads (persistent pool: "
-                     "%d workers + the caller, the reference's default)" % (a["frames"], a["seconds"], a["cores"], a["cores"] - 1),
-           "cpus_online": online, "cpus_usable": quota}
-    if quota < online:
-        b = sample(quota - 1, 7.0)
-        b["sample"] = "the same with %d threads = the CPUs the cgroup lets this process use" % b["cores"]
-        out["at_usable_cpus"] = b
+
+    def describe(a, what):
+        return "%d consecutive frames of the same 1920x1080 BoxScene(6) rotation in one C call, %.1f s, %d threads (persistent pool: %d workers + " \
+               "the caller%s)" % (a["frames"], a["seconds"], a["cores"], a["cores"] - 1, what)
+
+    if quota >= online:
+        a = sample(-1, 12.0)               # threads = hardware_concurrency() - 1 + the caller, as BlockingRenderer()
+        out = dict(a, unit="Mrays/s", kind="port", sample=describe(a, ", the reference's default"))
+    else:
+        # a cgroup quota below the CPU count: the reference's default thread count oversubscribes it.  `value` is the sample with
+        # as many threads as CPUs the process may use; the default-thread-count sample is reported beside it.
+        a = sample(quota - 1, 7.0)
+        out = dict(a, unit="Mrays/s", kind="port", sample=describe(a, "; = the CPUs the cgroup lets this process use"))
+        b = sample(-1, 7.0)
+        out["reference_default_threads"] = dict(b, sample=describe(b, ", the reference's default, on %d usable CPUs" % quota))
+    out["cpus_online"] = online
+    out["cpus_usable"] = quota
+    for k in ("frames", "seconds"):
+        out.pop(k, None)
     return out
 
 
