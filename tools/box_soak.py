@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""BoxScene soak (development aid): random cameras, full 1080p RGBX8 frames rendered in one multi-frame launch, every
-frame compared with the oracle byte for byte.  python3 tools/box_soak.py [frames_per_dimension]"""
+"""BoxScene soak (development aid): random cameras, full 1080p frames rendered in one multi-frame launch, every frame
+compared with the oracle byte for byte.  python3 tools/box_soak.py [frames_per_dimension [rgbx8|rgbf32 [seed [dims]]]]"""
 import ctypes as C
 import os
 import sys
@@ -21,13 +21,19 @@ RGBX = [(8, 1, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0, 0, 0)]
 
 def main():
     per_dim = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+    chans = RGBX if len(sys.argv) < 3 or sys.argv[2] == "rgbx8" else [(32, 1, 0, 0, 0, True), (32, 0, 1, 0, 0, True), (32, 0, 0, 1, 0, True)]
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 900
+    dims = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [3, 4, 6, 8, 10]
     w, h = 1920, 1080
-    fmt = ntracer_amd.ImageFormat(w, h, [ntracer_amd.Channel(*c) for c in RGBX])
+    fmt = ntracer_amd.ImageFormat(w, h, [ntracer_amd.Channel(*c) for c in chans])
     st = fmt._as_struct()
-    threads = max(1, min(200, (os.cpu_count() or 2) - 1))
+    sys.path.insert(0, ROOT)
+    import bench
+    threads = max(1, min(200, bench.cpu_quota_cores() - 1))
     bad = 0
-    for n in (3, 4, 6, 8, 10):
-        rng = np.random.default_rng(900 + n)
+    RGBX_ = chans
+    for n in dims:
+        rng = np.random.default_rng(seed + n)
         origins, axes = [], []
         for k in range(per_dim):
             q, _ = np.linalg.qr(rng.standard_normal((n, n)))
@@ -53,7 +59,7 @@ def main():
         nbad = 0
         for f in range(per_dim):
             osc.set_camera(o[f], a[f])
-            ref = osc.render(w, h, RGBX, threads=threads)
+            ref = osc.render(w, h, RGBX_, threads=threads)
             d = int((got[f] != ref).sum())
             if d:
                 nbad += 1
