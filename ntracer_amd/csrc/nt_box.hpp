@@ -595,15 +595,23 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
 // bit rendered with the complete box_pixel -- classification, box_resolve, box_color.
 // F32: three plain fp32 channels instead of packed RGB.  ZERO: hand the word back zeroed (the fused path's bitmap is
 // marked with atomic ORs by box_tile_kernel and must be clean when the next launch starts).
-template <int N, bool F32 = false, bool ZERO = false>
+// SPLIT (small launches, ZERO only): 2 or 4 waves per word, wave k for the stretches k, k + SPLIT, ... -- the marked stretches
+// of a row come in runs, and with few rows in flight a run of ten is a long tail for one wave.
+template <int N, bool F32 = false, bool ZERO = false, int SPLIT = 1>
 __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarget tg) {
     const int tid = (int)threadIdx.x;
-    const int row = (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "waves per redo word");
+    const int row = (int)blockIdx.y * (4 / SPLIT) + wv / SPLIT;
     if (row >= tg.row_count) return;
     uint32_t *word = tg.redo + ((size_t)blockIdx.z * tg.row_count + row) * tg.redo_words + blockIdx.x;
-    uint32_t todo = *word;
+    const uint32_t mine = (SPLIT == 1 ? 0xffffffffu : SPLIT == 2 ? 0x55555555u : 0x11111111u) << (wv % SPLIT);
+    uint32_t todo = *word & mine;
     if (todo == 0u) return;
-    if (ZERO && (tid & 63) == 0) *word = 0u;
+    if (ZERO && (tid & 63) == 0) {
+        if (SPLIT > 1) atomicAnd(word, ~mine);  // (the other waves may not have read the word yet: each needs its own bits only)
+        else *word = 0u;
+    }
     float org[N], right[N], up[N], fwd[N], dir[N];
     load_camera<N>(cam, org, right, up, fwd);
     float margin = fabsf(org[0]);
@@ -775,9 +783,12 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
 //                                   word back zeroed, so the bitmap is clean for the next launch (the host zeroes it once).
 // No pre-kernel; the only scratch is the bitmap (one bit per 64 pixels).
 // --------------------------------------------------------------------------------------
-template <int N, bool F32, int ROWS>
-__global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
+// WAVES: waves per block, i.e. the tile is 64 x WAVES*ROWS pixels -- 4 unless fewer leave fewer idle waves below the last row
+// of the launch (a rank's 136 rows of a 1080-row frame: three tiles of 48 rows instead of three of 64).
+template <int N, bool F32, int ROWS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
     static_assert(ROWS == 8 || ROWS == 16, "sixteen row codes to a qword");
+    static_assert(WAVES >= 2 && WAVES <= 4, "two to four waves a block");
     constexpr int R = ROWS;
     __shared__ uint32_t s_code[64];
     const int tid = (int)threadIdx.x;
@@ -796,13 +807,13 @@ __global__ __launch_bounds__(256) void box_tile_kernel(NtCameraFixed cam, NtTarg
     } else {
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
     }
-    const int tile_row0 = (int)blockIdx.y * 4 * R;
+    const int tile_row0 = (int)blockIdx.y * WAVES * R;
     // ---- phase 1: the tile's stretch codes, one row per lane of one wave -- a different one from block to block, so that
     // the extra work does not always land on the same SIMD of a CU
-    if (wv == (int)((blockIdx.x + blockIdx.y + blockIdx.z) & 3u)) {
+    if (wv == (int)((blockIdx.x + blockIdx.y + blockIdx.z) % (unsigned)WAVES)) {
         uint32_t code = 0u;
         const int trow = tile_row0 + lane;
-        if (lane < 4 * R && trow < tg.row_count) {
+        if (lane < WAVES * R && trow < tg.row_count) {
             const int orow = tg.row_begin + trow;
             int y = orow;
             if (tg.band_world > 1) {
@@ -1045,18 +1056,33 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         // tiles of 64 rows would hang much further over the bottom of the launch than tiles of 32
         const long long waves8 = (long long)((tg.width + 63) / 64) * ((tg.row_count + 31) / 32) * li.nframes * 4;
         const bool r16 = waves8 >= 64 * 1024;
-        const dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + (r16 ? 63 : 31)) / (r16 ? 64 : 32)), (unsigned)li.nframes);
+        // waves per block (large launches): the count that leaves the fewest idle waves below the last row
+        int wpb = 4;
+        if (r16) {
+            const int groups = (tg.row_count + 15) / 16;                   // waves with rows, per column
+            if ((groups + 2) / 3 * 3 < (groups + 3) / 4 * 4) wpb = 3;
+        }
+        const int tile_rows = wpb * (r16 ? 16 : 8);
+        const dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + tile_rows - 1) / tile_rows), (unsigned)li.nframes);
         tg.redo_words = ((tg.width + 63) / 64 + 31) / 32;
         tg.redo = li.cull_buf;                        // [frame][row][redo_words], all zero between launches
-        const dim3 rgrid((unsigned)tg.redo_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes);
+        // few rows in flight: two waves per redo word
+        const long long rwords = (long long)tg.row_count * li.nframes * tg.redo_words;
+        const int split = rwords < 96 * 1024 ? 2 : 1;           // (four waves a word measured slower than two)
+        const int rpb = 4 / split;              // rows per block
+        const dim3 rgrid((unsigned)tg.redo_words, (unsigned)((tg.row_count + rpb - 1) / rpb), (unsigned)li.nframes);
         if (fmt_rgb) {
-            if (r16) hipLaunchKernelGGL((box_tile_kernel<N, false, 16>), tgrid, dim3(256), 0, st, cf, tg);
-            else hipLaunchKernelGGL((box_tile_kernel<N, false, 8>), tgrid, dim3(256), 0, st, cf, tg);
-            hipLaunchKernelGGL((box_redo_kernel<N, false, true>), rgrid, dim3(256), 0, st, cf, tg);
+            if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, false, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
+            else if (r16) hipLaunchKernelGGL((box_tile_kernel<N, false, 16, 4>), tgrid, dim3(256), 0, st, cf, tg);
+            else hipLaunchKernelGGL((box_tile_kernel<N, false, 8, 4>), tgrid, dim3(256), 0, st, cf, tg);
+            if (split == 2) hipLaunchKernelGGL((box_redo_kernel<N, false, true, 2>), rgrid, dim3(256), 0, st, cf, tg);
+            else hipLaunchKernelGGL((box_redo_kernel<N, false, true, 1>), rgrid, dim3(256), 0, st, cf, tg);
         } else {
-            if (r16) hipLaunchKernelGGL((box_tile_kernel<N, true, 16>), tgrid, dim3(256), 0, st, cf, tg);
-            else hipLaunchKernelGGL((box_tile_kernel<N, true, 8>), tgrid, dim3(256), 0, st, cf, tg);
-            hipLaunchKernelGGL((box_redo_kernel<N, true, true>), rgrid, dim3(256), 0, st, cf, tg);
+            if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
+            else if (r16) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 4>), tgrid, dim3(256), 0, st, cf, tg);
+            else hipLaunchKernelGGL((box_tile_kernel<N, true, 8, 4>), tgrid, dim3(256), 0, st, cf, tg);
+            if (split == 2) hipLaunchKernelGGL((box_redo_kernel<N, true, true, 2>), rgrid, dim3(256), 0, st, cf, tg);
+            else hipLaunchKernelGGL((box_redo_kernel<N, true, true, 1>), rgrid, dim3(256), 0, st, cf, tg);
         }
         return 0;
     }
@@ -1082,7 +1108,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
             hipLaunchKernelGGL((box_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
         }
         if (BoxRows<N>::value > 1)
-            hipLaunchKernelGGL((box_redo_kernel<N, false, false>), dim3((unsigned)tg.redo_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes),
+            hipLaunchKernelGGL((box_redo_kernel<N, false, false, 1>), dim3((unsigned)tg.redo_words, (unsigned)((tg.row_count + 3) / 4), (unsigned)li.nframes),
                                dim3(256), 0, (hipStream_t)li.stream, cf, tg);
     } else {
         hipLaunchKernelGGL((box_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)li.stream, cf, tg);
