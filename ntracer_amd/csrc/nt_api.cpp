@@ -1126,6 +1126,20 @@ int nt_calculate_color(nt_scene_t *s, int x, int y, int width, int height, float
     return nt_colors_at(s, width, height, 1, &xs, &ys, rgb, -1);
 }
 
+#ifdef NT_DEBUG_SCRATCH
+// Diagnostic builds only (tools/box_census.py; not part of include/ntracer_hip.h): the BoxScene scratch of the last launch
+// on `device` (stretch codes / redo words of the cull / box / redo path), after the device has drained.
+long long nt_debug_box_scratch(nt_scene_t *s, int device, void *out, size_t bytes) {
+    if (!s || !out) return fail(NT_E_INVALID, "NULL argument");
+    auto it = s->devs.find(device);
+    if (it == s->devs.end() || !it->second->cull.p) return fail(NT_E_INVALID, "no BoxScene launch on this device yet");
+    if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(NT_E_DEVICE, "device synchronisation failed");
+    const size_t n = std::min(bytes, it->second->cull.cap);
+    if (hipMemcpy(out, it->second->cull.p, n, hipMemcpyDeviceToHost) != hipSuccess) return fail(NT_E_DEVICE, "copy failed");
+    return (long long)n;
+}
+#endif
+
 int nt_scene_last_stats(const nt_scene_t *cs, nt_stats *out) {
     nt_scene *s = const_cast<nt_scene *>(cs);
     if (!s || !out) return fail(NT_E_INVALID, "NULL argument");
