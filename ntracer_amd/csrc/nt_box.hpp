@@ -703,18 +703,22 @@ __device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], cons
         tlo = fmaxf(tlo, fmaxf(lo_a, lo_b));
         thi = fminf(thi, fminf(hi_a, hi_b));
         dead = dead || (pa == 0.0f && qa > 0.0f) || (pb == 0.0f && qb < 0.0f);
-        // the middle ray's entry into slab j (any K is verified below, so accuracy only matters for the yield)
-        const float nr = ((vc[j] < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc[j]);
-        tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);         // second-to-last entry
-        const bool later = nr > tn;
-        vK = later ? vc[j] : vK;
-        gK = later ? g[j] : gK;
-        oK = later ? org[j] : oK;
-        K = later ? j : K;
-        tn = fmaxf(tn, nr);
     }
     if (!(dead || tlo > thi)) {                      // a NaN keeps the stretch
         code = 15u;
+        // the middle ray's entries into the slabs: the last one, K, and the one before it (any K is verified below, so
+        // accuracy only matters for the yield).  Only for stretches that survive: most tiles have none.
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float nr = ((vc[j] < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc[j]);
+            tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);         // second-to-last entry
+            const bool later = nr > tn;
+            vK = later ? vc[j] : vK;
+            gK = later ? g[j] : gK;
+            oK = later ? org[j] : oK;
+            K = later ? j : K;
+            tn = fmaxf(tn, nr);
+        }
         const float vKa = vK - gK, vKb = vK + gK;
         if (N <= 14 && vKa * vKb > 0.0f) {
             const float num = (vK < 0.0f ? 1.0f : -1.0f) - oK;
@@ -934,15 +938,26 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 q = q < tg.plain_maxval ? q : tg.plain_maxval;
                 emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
             }
+            // (the one-face rows of a wave mostly share their face: its component of `base` is picked once)
+            uint32_t K0 = 0u;
+            float bK0 = base[0];
+            if (inner != 0ull) {
+                K0 = ((uint32_t)(rowcodes >> (__builtin_ctzll(inner) & 60)) & 15u) - 1u;
+#pragma unroll
+                for (int j = 1; j < N; ++j) bK0 = K0 == (uint32_t)j ? base[j] : bK0;
+            }
             while (inner != 0ull) {
                 const int rr = __builtin_ctzll(inner) >> 2;
                 inner &= inner - 1ull;
                 const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
                 const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
                 const float usK = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_usK), rr));
-                float bK = base[0];
+                float bK = bK0;
+                if (K != K0) {
+                    bK = base[0];
 #pragma unroll
-                for (int j = 1; j < N; ++j) bK = K == (uint32_t)j ? base[j] : bK;
+                    for (int j = 1; j < N; ++j) bK = K == (uint32_t)j ? base[j] : bK;
+                }
                 const float dK = bK - usK;                                // dir[K], bit for bit
                 const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
                 const float t = (fabsf(dK) * __builtin_amdgcn_rsqf(sqa)) * maxv, th = t * 0.5f;
@@ -983,20 +998,32 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 const long long off = NT_ROW_OFF(rr);
                 emit_f32x3(tg, off, r, gb);
             }
+            uint32_t K0 = 0u;
+            float bK0 = base[0];
+            if (inner != 0ull) {
+                K0 = ((uint32_t)(rowcodes >> (__builtin_ctzll(inner) & 60)) & 15u) - 1u;
+#pragma unroll
+                for (int j = 1; j < N; ++j) bK0 = K0 == (uint32_t)j ? base[j] : bK0;
+            }
             while (inner != 0ull) {
                 // one face K throughout: sine = d_K * (-sign d_K) <= 0, shade = -sine (tracer.hpp:105-107)
                 const int rr = __builtin_ctzll(inner) >> 2;
                 inner &= inner - 1ull;
                 const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
                 const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+                const float usK = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_usK), rr));
 #pragma unroll
                 for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
                 float sq = dir[0] * dir[0];
 #pragma unroll
                 for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-                float xk = dir[0];
+                float bK = bK0;
+                if (K != K0) {
+                    bK = base[0];
 #pragma unroll
-                for (int j = 1; j < N; ++j) xk = K == (uint32_t)j ? dir[j] : xk;
+                    for (int j = 1; j < N; ++j) bK = K == (uint32_t)j ? base[j] : bK;
+                }
+                const float xk = bK - usK;                                // dir[K], bit for bit (the same two operations)
                 const float shade = fabsf(xk / sqrt_wave(sq));
                 const long long off = NT_ROW_OFF(rr);
                 emit_f32x3(tg, off, shade * 1.0f, shade * 0.5f);
