@@ -421,6 +421,7 @@ void fill_composite(const nt_scene *s, const DeviceState *ds, NtCompositeDev &c,
     c.n_triangles = s->n_triangles;
     c.stats = stats ? (unsigned long long *)ds->stats.p : nullptr;
     c.checked = nullptr;
+    c.alias_normals = 0;
     c.checked_words = 0;
     c.checked_lanes = 0;
 }
@@ -567,8 +568,11 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         // composite_kernel_t<N, true>), which needs the reference's exact `checked` list: a bitmap column per resident
         // lane.  NTRACER_CLEAN_NORMALS=1 selects the intended semantics instead (a hit keeps the normal of what was hit).
         const char *ecl = getenv("NTRACER_CLEAN_NORMALS");
-        const bool faithful = s->n <= NT_MAX_FIXED_DIM && (!s->all_opaque || s->n_solids > 0) && !job.stats && !(ecl && atoi(ecl) != 0);
+        const bool clean = ecl && atoi(ecl) != 0;
+        const bool faithful = s->n <= NT_MAX_FIXED_DIM && (!s->all_opaque || (s->n_solids > 0 && !clean && !job.stats));
         if (faithful) {
+            // (transparent materials need the exact list in either mode: the reference trims its transparent hits with the
+            // distance of the LAST test, so a repeated test is not harmless there)
             const long long words = ((long long)s->n_batches + s->n_triangles + s->n_solids + 31) / 32;
             long long tiles = job.colors_out ? (job.probe_count + 255) / 256
                                              : (long long)((tg.width + 15) / 16) * ((tg.row_count + 15) / 16) * job.nframes;
@@ -578,6 +582,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             c.checked = (uint32_t *)ds->checked.p;
             c.checked_words = (int)words;
             c.checked_lanes = (int)(blocks * 256);
+            c.alias_normals = clean ? 0 : 1;
         }
         // image renders of opaque scenes made of batches go through the packet kernel (primary rays share the
         // camera origin): it needs the camera table in device memory (and, for the persistent variant, a counter)

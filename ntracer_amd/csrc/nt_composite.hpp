@@ -1038,7 +1038,9 @@ __device__ __noinline__ bool leaf_closest_t(const NtCompositeDev &sc, const Wave
     for (int i = 0; i < count; ++i) {
         const int item = sc.items[start + i];
         if ((item & 3) != 0 && item == skip_item) continue;
-        if (ALIAS ? checked_seen(ck, item) : mbox_seen(w, lane, item)) continue;
+        // the reference's exact `checked` list in both modes: a repeated test is not harmless here -- the trim below uses the
+        // LAST test's distance (tracer.hpp:1084), so a test the reference skips changes which transparent hits survive
+        if (checked_seen(ck, item)) continue;
         int l;
         float t;
         if (ALIAS) {
@@ -1087,8 +1089,7 @@ __device__ __noinline__ bool trace_closest_t(const NtCompositeDev &sc, const Wav
     hit.item = -1;
     hit.lane = -1;
     th.n = 0;
-    if (ALIAS) checked_reset(ck);
-    else mbox_reset(w, lane);
+    checked_reset(ck);
     int node = sc.root;
     int sp = 0;
     int dirty = 0;
@@ -1441,9 +1442,9 @@ __device__ __noinline__ Color3 composite_color_t(const NtCompositeDev &sc, const
     return result;
 }
 
-// ALIAS = false: one block per 16x16 tile (grid = tiles).  ALIAS = true: the blocks stride over the tiles (tiles_x *
-// tiles_y * frames of them), because every resident lane owns a column of the `checked` bitmap and that scratch is sized by
-// the grid, not by the image.
+// The blocks stride over the tiles (tiles_x * tiles_y * frames of them): every resident lane owns a column of the `checked`
+// bitmap, and that scratch is sized by the grid, not by the image.  ALIAS: the reference's o_hit.normal handling (see above);
+// otherwise a hit keeps the normal of what was hit.
 template <int N, bool ALIAS>
 __global__ __launch_bounds__(256) void composite_kernel_t(NtCameraFixed cam_in, NtCompositeDev sc, NtTarget tg, int tiles_x, int tiles_y, int frames) {
     extern __shared__ float2 lds_raw[];
@@ -1452,7 +1453,7 @@ __global__ __launch_bounds__(256) void composite_kernel_t(NtCameraFixed cam_in, 
     const int wv = tid >> 6;
     const WaveLds w = wave_lds(reinterpret_cast<char *>(lds_raw), wv, sc.stack_depth, N);
     Checked ck;
-    ck.bits = ALIAS ? sc.checked + ((long long)blockIdx.x * 256 + tid) : nullptr;
+    ck.bits = sc.checked + ((long long)blockIdx.x * 256 + tid);
     ck.stride = sc.checked_lanes;
     ck.words = sc.checked_words;
     ck.n_batches = sc.n_batches;
@@ -1461,19 +1462,16 @@ __global__ __launch_bounds__(256) void composite_kernel_t(NtCameraFixed cam_in, 
     if (tg.colors_out) { px = 0; py = 0; }
     else { px = (wv & 1) * 8 + (lane & 7); py = (wv >> 1) * 8 + (lane >> 3); }
     const long long total = (long long)tiles_x * tiles_y * frames;
-    for (long long tile = ALIAS ? (long long)blockIdx.x : 0; tile < (ALIAS ? total : 1); tile += gridDim.x) {
-        int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
-        if (ALIAS) {
-            bz = (int)(tile / ((long long)tiles_x * tiles_y));
-            const int rem = (int)(tile - (long long)bz * tiles_x * tiles_y);
-            by = rem / tiles_x;
-            bx = rem - by * tiles_x;
-        }
+    for (long long tile = (long long)blockIdx.x; tile < total; tile += gridDim.x) {
+        const int bz = (int)(tile / ((long long)tiles_x * tiles_y));
+        const int rem = (int)(tile - (long long)bz * tiles_x * tiles_y);
+        const int by = rem / tiles_x;
+        const int bx = rem - by * tiles_x;
         const PixelRef pr = locate_pixel_at<16, 16>(tg, bx, by, bz, px, py, tid);
         if (pr.valid) {
             NtCameraFixed cam = cam_in;
             float org[N], right[N], up[N], fwd[N], dir[N];
-            if (cam.buf) cam.buf += (size_t)bz * 4 * N - (size_t)blockIdx.z * 4 * N;        // load_camera indexes by blockIdx.z
+            if (cam.buf) cam.buf += (size_t)bz * 4 * N;            // (load_camera adds blockIdx.z, which is 0 here)
             load_camera<N>(cam, org, right, up, fwd);
             primary_dir<N>(tg, right, up, fwd, pr.x, pr.y, dir);
             const Color3 c = composite_color_t<N, ALIAS>(sc, w, lane, org, dir, ck);
@@ -2151,17 +2149,21 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
     }
     const bool feat = sc.n_point_lights || sc.n_global_lights || sc.any_reflective || sc.has_scalar_prims;
     hipStream_t s = (hipStream_t)li.stream;
-    if (sc.checked && !sc.stats) {
-        // reference-faithful normals: as many blocks as the `checked` scratch has lane columns for, striding over the tiles
+    if (sc.checked) {
+        // transparent materials, or the reference's o_hit.normal handling for scenes with Solids: the kernel with the exact
+        // `checked` list -- as many blocks as the scratch has lane columns for, striding over the tiles
         const long long tiles = (long long)grid.x * grid.y * grid.z;
         long long blocks = sc.checked_lanes / 256;
         if (blocks > tiles) blocks = tiles;
-        hipLaunchKernelGGL((composite_kernel_t<N, true>), dim3((unsigned)blocks), dim3(256), lds, s, cf, sc, tg, (int)grid.x, (int)grid.y, (int)grid.z);
+        if (sc.alias_normals)
+            hipLaunchKernelGGL((composite_kernel_t<N, true>), dim3((unsigned)blocks), dim3(256), lds, s, cf, sc, tg, (int)grid.x, (int)grid.y, (int)grid.z);
+        else
+            hipLaunchKernelGGL((composite_kernel_t<N, false>), dim3((unsigned)blocks), dim3(256), lds, s, cf, sc, tg, (int)grid.x, (int)grid.y, (int)grid.z);
         return 0;
     }
     if (!sc.all_opaque) {
-        hipLaunchKernelGGL((composite_kernel_t<N, false>), grid, dim3(256), lds, s, cf, sc, tg, (int)grid.x, (int)grid.y, (int)grid.z);
-        return 0;
+        snprintf(nt_launch_error_buf(), NT_LAUNCH_ERROR_LEN, "internal: transparent scene without the checked-list scratch");
+        return -1;
     }
     // scenes with unbatched triangles or solids take the packet walk only as the first of two passes (their hits
     // are shaded by the general kernel)

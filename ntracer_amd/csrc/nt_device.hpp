@@ -125,6 +125,7 @@ struct NtCompositeDev {
     // One bit per (resident lane, primitive): checked[word * checked_lanes + lane slot]; nullptr selects the "clean"
     // semantics with the 16-slot mailbox.
     uint32_t *checked;
+    int alias_normals;        // 1: the reference's o_hit.normal handling; 0: a hit keeps the normal of what was hit (NTRACER_CLEAN_NORMALS)
     int checked_words;        // ceil((n_batches + n_triangles + n_solids) / 32)
     int checked_lanes;        // lane slots = blocks of the launch * 256
     int n_triangles;

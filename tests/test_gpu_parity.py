@@ -1035,6 +1035,32 @@ def test_reflection_deeper_than_the_level_stack(monkeypatch):
         assert np.abs(img - np.clip(o, 0, 1).reshape(h, w, 3)).max() < TOL_ORACLE, force_var
 
 
+def test_five_dimensional_feature_scene_vs_reference(monkeypatch):
+    """feature5_n5 (captured from the reference's tracer5: transparent and reflective simplices, Solids, lights, shadows,
+    reflection) through composite_kernel_t<5, true>: the reference's colours on every sample (1e-4, north_star's tolerance),
+    the default-mode oracle's to 1e-5; with NTRACER_CLEAN_NORMALS=1 the clean-mode oracle's."""
+    g = fx.load("feature5_n5")
+    flat = fx.flat_of(g)
+    p = fx.params_of(g)
+    sc = tracern.CompositeScene.from_flat(5, flat)
+    sc.set_params_flat(p)
+    for clean in (False, True):
+        if clean:
+            monkeypatch.setenv("NTRACER_CLEAN_NORMALS", "1")
+        for k, f in enumerate(g["frames"]):
+            sc._set_camera_arrays(g["origins"][f], g["axes"][f])
+            c = sc.colors_at(g["xs"], g["ys"], 160, 100)
+            o = ob.OracleScene(5, g["origins"][f], g["axes"][f], flat=flat, params=p, clean_normals=clean).colors_at(g["xs"], g["ys"], 160, 100)
+            assert np.abs(c - o).max() < TOL_ORACLE, (int(f), clean)
+            if not clean:
+                assert np.abs(c - g["colors"][k]).max() < TOL_REF, int(f)
+    monkeypatch.delenv("NTRACER_CLEAN_NORMALS")
+    sc._set_camera_arrays(g["origins"][9], g["axes"][9])
+    img = render_host(sc, fmt_of(160, 100, fx.RGBF32))
+    ref = ob.OracleScene(5, g["origins"][9], g["axes"][9], flat=flat, params=p).render(160, 100, fx.RGBF32, threads=7)
+    assert np.abs(img.view(">f4") - ref.view(">f4")).max() < TOL_ORACLE
+
+
 def test_shadow_rays_are_counted():
     g = fx.load("feature3d")
     flat = fx.flat_of(g, opaque=True)

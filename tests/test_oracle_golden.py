@@ -130,6 +130,23 @@ def test_twelve_dimensional_lit_scene_matches_the_generic_reference_module():
     assert bad <= 0.005 * total, bad
 
 
+def test_five_dimensional_feature_scene_matches_the_reference():
+    """feature5_n5, rendered by the reference's tracer5: opaque / reflective / transparent / transparent + reflective
+    simplices (batched and loose), a Solid cube, a transparent Solid sphere, point + global light, shadows, reflection depth 3.
+    The default mode (o_hit.normal aliasing reproduced) agrees on every sample; the clean mode does not."""
+    g = fx.load("feature5_n5")
+    flat = fx.flat_of(g)
+    assert len(flat["solid_recs"]) == 2 and len(flat["tri_recs"]) == 3 and (np.asarray(flat["materials"])[:, 6] < 1).sum() == 2
+    p = fx.params_of(g)
+    differ_clean = 0
+    for k, f in enumerate(g["frames"]):
+        c = ob.OracleScene(5, g["origins"][f], g["axes"][f], flat=flat, params=p).colors_at(g["xs"], g["ys"], 160, 100)
+        assert np.abs(c - g["colors"][k]).max() < TOL, int(f)
+        cc = ob.OracleScene(5, g["origins"][f], g["axes"][f], flat=flat, params=p, clean_normals=True).colors_at(g["xs"], g["ys"], 160, 100)
+        differ_clean += int((np.abs(cc - g["colors"][k]).max(axis=1) > TOL).sum())
+    assert differ_clean > 10
+
+
 def test_clean_mode_only_differs_where_the_alias_bites():
     g = fx.load("cell600_n4")
     f = g["frames"][1]

@@ -570,6 +570,58 @@ def gen_lit12():
           "solids", len(d["solid_recs"]), "hit fraction", float((np.abs(cols[..., 0] - cols[..., 1]) > 1e-6).mean()))
 
 
+def gen_feature5():
+    """A 5-D scene through the reference's tracer5 module with everything the composite path has: facets of a 5-simplex in
+    opaque, reflective, transparent and transparent + reflective materials, a Solid cube and a Solid sphere (one transparent),
+    a point light, a global light, shadows, reflection depth 3.  Built by the reference's own builder."""
+    import random
+    n = 5
+    nt = NTracer(n)
+    V = nt.Vector
+    mats = [Material((1, 0.5, 0.5)), Material((0.3, 0.8, 0.4), 1, 0.3, 0.7, 10, (1, 1, 0.7)), Material((0.3, 0.4, 1.0), 0.5, 0, 1, 8),
+            Material((0.8, 0.6, 0.1), 0.7, 0.2, 0.5, 5, (0.5, 1, 1)), Material((0.85, 0.85, 0.9), 1, 0, 0, 8)]
+    pts = [[1.0 if k == i else 0.0 for k in range(n)] for i in range(n)]
+    pts.append([(1 - math.sqrt(n + 1)) / n] * n)
+    centre = [sum(p[k] for p in pts) / (n + 1) for k in range(n)]
+    # (stretched a little differently along every axis: a regular simplex is symmetric under swapping the axes the camera
+    # never turns into, and two of its facets would then tie along whole regions of rays)
+    pts = [[2.2 * (1 + 0.04 * k) * (p[k] - centre[k]) for k in range(n)] for p in pts]
+    protos = []
+    for skip in range(n + 1):
+        protos.append(nt.TrianglePrototype([V(*p) for i, p in enumerate(pts) if i != skip], mats[skip % 4]))
+    rnd = random.Random(77)
+    for i in range(9):                        # a cloud of small simplices around it
+        c = [rnd.uniform(-2.5, 2.5) for _ in range(n)]
+        protos.append(nt.TrianglePrototype([V(*[c[k] + rnd.uniform(-0.8, 0.8) for k in range(n)]) for _ in range(n)], mats[i % 5]))
+    ax = lambda i: V.axis(i, 1)
+    rot = nt.Matrix.rotation(ax(0), ax(1), 0.4) * nt.Matrix.rotation(ax(2), ax(4), 0.3) * nt.Matrix.scale(0.8)
+    protos.append(nt.SolidPrototype(W.CUBE, V(2.3, -1.0, 0.4, 0.1, -0.2), rot, mats[4]))
+    protos.append(nt.SolidPrototype(W.SPHERE, V(-2.1, 1.3, -0.3, 0.2, 0.0), nt.Matrix.scale(0.9), mats[3]))
+    scene = nt.build_composite_scene(protos)
+    scene.add_light(nt.PointLight(V(5.0, 6.0, -7.0, 2.0, 1.0), (3e4, 2.8e4, 2.5e4)))
+    scene.add_light(nt.GlobalLight(V(0.2, -0.9, 0.3, 0.1, 0.05).unit(), (0.4, 0.4, 0.5)))
+    scene.set_ambient_color((0.03, 0.03, 0.04))
+    scene.set_shadows(True)
+    scene.set_max_reflect_depth(3)
+    fl = Flattener(nt)
+    d = fl.arrays(scene)
+    cam_distance = -2.2 * 4
+    origins, axes = rotation_cameras(nt, cam_distance, frames=40)
+    w, h = 160, 100
+    frames = [0, 9, 21, 34]
+    xs, ys = lattice(w, h, 2, 2, 1, 0)
+    cols = np.zeros((len(frames), len(xs), 3), np.float32)
+    for k, f in enumerate(frames):
+        set_cam(nt, scene, origins[f], axes[f])
+        cols[k] = colors_at(scene, xs, ys, w, h)
+    d.update(scene_params(scene))
+    d.update(origins=origins, axes=axes, cam_distance=np.float32(cam_distance), frames=np.array(frames, np.int32),
+             xs=xs, ys=ys, colors=cols, width=np.int32(w), height=np.int32(h))
+    np.savez_compressed(os.path.join(OUT, "feature5_n5.npz"), **d)
+    print("wrote feature5_n5 nodes", len(d["node_axis"]), "items", len(d["items"]), "batches", len(d["batch_recs"]), "tris", len(d["tri_recs"]),
+          "solids", len(d["solid_recs"]), "hit fraction", float((np.abs(cols[..., 0] - cols[..., 1]) > 1e-6).mean()))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -588,6 +640,7 @@ if __name__ == "__main__":
         # a 5-D cross-polytope-like {3,3,3,4}: 32 facets, fixed<5> module
         "orthoplex5": lambda: gen_polytope("orthoplex5_n5", ["3", "3", "3", "4"], 320, 200, [0, 9, 47, 120], (5, 3)),
         "lit12": gen_lit12,
+        "feature5": gen_feature5,
     }
     for k, f in jobs.items():
         if a.only is None or k in a.only:
