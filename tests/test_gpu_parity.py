@@ -415,7 +415,7 @@ def test_run_time_n_kernel_has_the_feature_set_of_the_fixed_ones(monkeypatch):
         sct.colors_at(xs.ravel()[:64], ys.ravel()[:64], w, h)
 
 
-@pytest.mark.parametrize("name", ["cell600_n4", "cell120_n4", "orthoplex5_n5", "simplex10_n10"])
+@pytest.mark.parametrize("name", ["cell600_n4", "cell120_n4", "orthoplex5_n5", "simplex7_n7", "simplex9_n9", "simplex10_n10"])
 def test_polytope_vs_oracle_and_reference(name):
     g = fx.load(name)
     n = int(g["dimension"])

@@ -65,7 +65,7 @@ def test_pack_pixel_edge_values():
     assert ob.pack_pixel([float("nan"), 0, 0], [(8, 1, 0, 0)]) == bytes([0])                     # SSE max(NaN,0) = 0
 
 
-@pytest.mark.parametrize("name", ["cell600_n4", "cell120_n4", "orthoplex5_n5", "simplex10_n10"])
+@pytest.mark.parametrize("name", ["cell600_n4", "cell120_n4", "orthoplex5_n5", "simplex7_n7", "simplex9_n9", "simplex10_n10"])
 def test_polytope_scene_matches_reference(name):
     g = fx.load(name)
     n = int(g["dimension"])

@@ -639,6 +639,9 @@ if __name__ == "__main__":
         "simplex10": lambda: gen_polytope("simplex10_n10", ["3"] * 9, 320, 200, [0, 9, 47, 120], (5, 3)),
         # a 5-D cross-polytope-like {3,3,3,4}: 32 facets, fixed<5> module
         "orthoplex5": lambda: gen_polytope("orthoplex5_n5", ["3", "3", "3", "4"], 320, 200, [0, 9, 47, 120], (5, 3)),
+        # 7-D and 9-D simplices: the reference's tracer7 module and its generic one (n = 9 has no specialised module there)
+        "simplex7": lambda: gen_polytope("simplex7_n7", ["3"] * 6, 320, 200, [0, 9, 47, 120], (5, 3)),
+        "simplex9": lambda: gen_polytope("simplex9_n9", ["3"] * 8, 320, 200, [0, 9, 47, 120], (5, 3)),
         "lit12": gen_lit12,
         "feature5": gen_feature5,
     }
