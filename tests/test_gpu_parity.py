@@ -682,10 +682,12 @@ def test_band_heights_other_than_32(band_rows, world):
     """nt_render_opts.band_rows: the ranks' compact buffers, de-interleaved with the same band height, give the
     whole frame -- BoxScene (64x4-pixel blocks) and a composite scene (16x16-pixel quads of the packet kernel)."""
     g = fx.load("cell600_n4")
-    scenes = [tracern.BoxScene(6), tracern.CompositeScene.from_flat(4, fx.flat_of(g))]
+    scenes = [tracern.BoxScene(6), tracern.CompositeScene.from_flat(4, fx.flat_of(g)), tracern.BoxScene(12)]
     gb = fx.load("box_n6_1920x1080")
     scenes[0]._set_camera_arrays(gb["origins"][21], gb["axes"][21])
     scenes[1]._set_camera_arrays(g["origins"][33], g["axes"][33])
+    g12 = fx.load("box_n12_320x200")                     # (run-time-n rows kernel)
+    scenes[2]._set_camera_arrays(g12["origins"][g12["frames"][1]], g12["axes"][g12["frames"][1]])
     fmt = fmt_of(500, 301, fx.RGBX8)
     for sc in scenes:
         whole = render_host(sc, fmt)
