@@ -83,6 +83,7 @@ struct DeviceState {
     DevBuf cull;                         // BoxScene: row culling bits
     bool cull_clean = false;             // `cull` is all zero (what the fused BoxScene path needs and leaves behind)
     DevBuf checked;                      // reference-faithful normals: the exact `checked` bitmap, one column per resident lane
+    DevBuf tframes;                      // run-time-n transparency kernel: the ray_color frame stacks, one column per resident lane
     // camera tables travel through pinned host memory (a pageable source makes hipMemcpyAsync wait for the copy on the
     // host, which stalls the launch pipeline of back-to-back calls): a ring of slots, each guarded by an event
     struct Stage { void *host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool in_flight = false; };
@@ -424,14 +425,12 @@ void fill_composite(const nt_scene *s, const DeviceState *ds, NtCompositeDev &c,
     c.alias_normals = 0;
     c.checked_words = 0;
     c.checked_lanes = 0;
+    c.tframes = nullptr;
+    c.tframe_count = 0;
 }
 
 int check_renderable(const nt_scene *s) {
     if (s->composite) {
-        if (s->n > NT_MAX_FIXED_DIM && !s->all_opaque)
-            return fail(NT_E_UNSUPPORTED, "composite scenes with more than %d dimensions do not support transparent materials", NT_MAX_FIXED_DIM);
-        if (!s->all_opaque && s->any_reflective && s->max_reflect_depth > 5)
-            return fail(NT_E_UNSUPPORTED, "max_reflect_depth > 5 is not supported for scenes with transparent materials");
         if (s->nodes.size() >= (1u << 24)) return fail(NT_E_UNSUPPORTED, "k-d trees with 2^24 or more nodes are not supported");
     }
     return NT_OK;
@@ -569,20 +568,34 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         // lane.  NTRACER_CLEAN_NORMALS=1 selects the intended semantics instead (a hit keeps the normal of what was hit).
         const char *ecl = getenv("NTRACER_CLEAN_NORMALS");
         const bool clean = ecl && atoi(ecl) != 0;
-        const bool faithful = s->n <= NT_MAX_FIXED_DIM && (!s->all_opaque || (s->n_solids > 0 && !clean && !job.stats));
+        const bool faithful = !s->all_opaque || (s->n_solids > 0 && !clean && !job.stats);
         if (faithful) {
             // (transparent materials need the exact list in either mode: the reference trims its transparent hits with the
             // distance of the LAST test, so a repeated test is not harmless there)
+            // The compile-time-N kernel keeps NT_TFRAMES ray_color frames in registers/scratch; above NT_MAX_FIXED_DIM, and
+            // for reflection deeper than that among transparent things, the run-time-n kernel with its frames in global
+            // scratch takes over (one wave per block there).
+            const char *efv = getenv("NTRACER_FORCE_VAR");
+            const int nframes_stack = s->any_reflective ? s->max_reflect_depth + 1 : 1;
+            const bool var_t = s->n > NT_MAX_FIXED_DIM || (efv && atoi(efv) != 0) || nframes_stack > 6;
+            const long long lpb = var_t ? 64 : 256;           // lanes per block
+            const long long tw = var_t ? 8 : 16;              // tile edge
             const long long words = ((long long)s->n_batches + s->n_triangles + s->n_solids + 31) / 32;
-            long long tiles = job.colors_out ? (job.probe_count + 255) / 256
-                                             : (long long)((tg.width + 15) / 16) * ((tg.row_count + 15) / 16) * job.nframes;
-            long long blocks = std::min<long long>(std::max<long long>(tiles, 1), 4096);
-            while (blocks > 64 && blocks * 256 * words * 4 > ((long long)256 << 20)) blocks /= 2;
-            if (int e = ds->checked.ensure((size_t)(blocks * 256 * words * 4))) return e;
+            const long long fwords = var_t ? (long long)nt_var_frame_words(s->n) * nframes_stack : 0;
+            long long tiles = job.colors_out ? (job.probe_count + lpb - 1) / lpb
+                                             : (long long)((tg.width + tw - 1) / tw) * ((tg.row_count + tw - 1) / tw) * job.nframes;
+            long long blocks = std::min<long long>(std::max<long long>(tiles, 1), var_t ? 8192 : 4096);
+            while (blocks > 64 && blocks * lpb * (words + fwords) * 4 > ((long long)512 << 20)) blocks /= 2;
+            if (int e = ds->checked.ensure((size_t)(blocks * lpb * words * 4))) return e;
             c.checked = (uint32_t *)ds->checked.p;
             c.checked_words = (int)words;
-            c.checked_lanes = (int)(blocks * 256);
+            c.checked_lanes = (int)(blocks * lpb);
             c.alias_normals = clean ? 0 : 1;
+            if (var_t) {
+                if (int e = ds->tframes.ensure((size_t)(blocks * lpb * fwords * 4))) return e;
+                c.tframes = (float *)ds->tframes.p;
+                c.tframe_count = nframes_stack;
+            }
         }
         // image renders of opaque scenes made of batches go through the packet kernel (primary rays share the
         // camera origin): it needs the camera table in device memory (and, for the persistent variant, a counter)
@@ -853,7 +866,7 @@ void nt_scene_destroy(nt_scene_t *s) {
         (void)hipDeviceSynchronize();
         for (DevBuf *b : {&ds->nodes, &ds->items, &ds->batch_recs, &ds->batch_mats, &ds->tri_recs, &ds->tri_mats, &ds->solid_recs,
                           &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams, &ds->counter,
-                          &ds->probes, &ds->stats, &ds->hits, &ds->numer, &ds->cull, &ds->checked})
+                          &ds->probes, &ds->stats, &ds->hits, &ds->numer, &ds->cull, &ds->checked, &ds->tframes})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
         for (auto &t : ds->tile_orders) t->buf.release();

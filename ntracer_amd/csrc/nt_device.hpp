@@ -129,6 +129,10 @@ struct NtCompositeDev {
     int checked_words;        // ceil((n_batches + n_triangles + n_solids) / 32)
     int checked_lanes;        // lane slots = blocks of the launch * 256
     int n_triangles;
+    // run-time-n transparency kernel (composite_kernel_var_t): the ray_color frame stacks in global scratch,
+    // tframes[(frame * words + word) * checked_lanes + lane slot], words = var_frame_words(n); nullptr = not that kernel
+    float *tframes;
+    int tframe_count;         // frames per lane slot: max_reflect_depth + 1 if anything reflects, else 1
 };
 
 // ---- launchers implemented in nt_var.hip (dispatch) over nt_inst_box.hip / nt_inst_composite.hip ----
@@ -155,4 +159,5 @@ struct NtLaunchInfo {
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 int nt_launch_composite(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg);
 int nt_launch_upload(void *stream, const float *src_pinned, float *dst, int count);
+int nt_var_frame_words(int n);   // floats per ray_color frame of composite_kernel_var_t
 const char *nt_launch_error();

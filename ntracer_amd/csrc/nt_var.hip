@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void box_rows_kernel_var(NtCamera cam, NtTarge
 // of them in turn -- while the vectors shading needs once per hit (normal ray, light vector, the saved view direction,
 // a Solid's local ray) sit in per-lane scratch memory.  Simplex and solid records are read component by component.
 // Operation order is the oracle's, so results equal the compile-time-N kernels' where both exist (NTRACER_FORCE_VAR=1).
-// Not here: transparent materials (refused by the host for n > 10).
+// Transparent materials, and the reference's o_hit.normal handling for scenes with Solids: composite_kernel_var_t below.
 // --------------------------------------------------------------------------------------
 struct VarLds {
     float2 *ray;     // [n][64] (origin, 1/direction; NaN marks direction == 0)
@@ -876,6 +876,632 @@ __device__ __noinline__ Color3 composite_color_var(const VarCtx &cx) {
     return result;
 }
 
+// --------------------------------------------------------------------------------------
+// Transparent materials, and the reference's o_hit.normal handling, at run-time n: composite_kernel_t (nt_composite.hpp)
+// restated with the current ray in LDS.  The ray_color frames -- one per reflection level, each with its ray, the walk's
+// normal ray and its surface list -- live in global scratch, [frame][word][lane slot], sized by the host for
+// max_reflect_depth + 1 levels: no depth limit here, which is why scenes with transparency whose depth is beyond the
+// compile-time-N kernel's frame stack are sent here as well, whatever their n.
+// --------------------------------------------------------------------------------------
+struct VarFrames {
+    float *base;             // this lane's column
+    long long stride;        // lane slots
+    int fw;                  // words per frame
+};
+// frame words: o[n] d[n] hn_o[n] hn_d[n], then the scalars below, then (NT_TH_MAX + 1) surfaces of 3 words
+enum { VF_DEPTH = 0, VF_SKIP_ITEM, VF_SKIP_LANE, VF_NSURF, VF_J, VF_R, VF_SPEC = VF_R + 3, VF_R0 = VF_SPEC + 3, VF_C = VF_R0 + 3,
+       VF_SPEC_A = VF_C + 3, VF_REFL, VF_SURF, VF_WORDS = VF_SURF + 3 * (NT_TH_MAX + 1) };
+__host__ __device__ __forceinline__ int var_frame_words(int n) { return 4 * n + VF_WORDS; }
+
+#define FRW(f, w) (fr.base[((long long)(f) * fr.fw + (w)) * fr.stride])
+#define FRI(f, w) (reinterpret_cast<int *>(fr.base)[((long long)(f) * fr.fw + (w)) * fr.stride])
+
+__device__ __forceinline__ Color3 fr_get3(const VarFrames &fr, int f, int w) { return c3(FRW(f, w), FRW(f, w + 1), FRW(f, w + 2)); }
+__device__ __forceinline__ void fr_put3(const VarFrames &fr, int f, int w, Color3 c) { FRW(f, w) = c.r; FRW(f, w + 1) = c.g; FRW(f, w + 2) = c.b; }
+
+// test_item (nt_composite.hpp) on the current ray
+__device__ __forceinline__ float test_item_var(const VarCtx &cx, int item, float cutoff, int skip_item, int skip_lane, int &lane_out) {
+    const NtCompositeDev &sc = cx.sc;
+    const int kind = item & 3, idx = item >> 2;
+    lane_out = -1;
+    if (kind == 0) {
+        const int sl = item == skip_item ? skip_lane : -1;
+        float min_t = cutoff;
+        int r = -1;
+        for (int l = 0; l < NT_DEV_BATCH; ++l) {
+            const float t = simplex_var(sc.batch_recs + ((size_t)idx * NT_DEV_BATCH + l) * sc.rec_stride, cx.n, cx.L, cx.lane, false, 0.0f);
+            if (l != sl && t != 0.0f && t < min_t) { min_t = t; r = l; }
+        }
+        lane_out = r;
+        return r >= 0 ? min_t : 0.0f;
+    }
+    if (kind == 1) return simplex_var(sc.tri_recs + (size_t)idx * sc.rec_stride, cx.n, cx.L, cx.lane, true, cutoff);
+    return solid_var(cx, idx, cutoff, false, nullptr, nullptr);
+}
+
+// the normal ray of a hit on the current ray (hit_normal in nt_composite.hpp)
+__device__ __forceinline__ void hit_normal_var(const VarCtx &cx, const Hit &hit, float *no, float *nd) {
+    const NtCompositeDev &sc = cx.sc;
+    const int n = cx.n;
+    const int kind = hit.item & 3, idx = hit.item >> 2;
+    if (kind == 2) {
+        solid_var(cx, idx, FLT_MAX, true, no, nd);
+        return;
+    }
+    const float *rec = kind == 0 ? sc.batch_recs + ((size_t)idx * NT_DEV_BATCH + hit.lane) * sc.rec_stride
+                                 : sc.tri_recs + (size_t)idx * sc.rec_stride;
+    float denom = 0.0f, fsq = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        const float fn = rec[1 + k];
+        const float pd = fn * VD(k);
+        denom = k == 0 ? pd : denom + pd;
+        fsq = k == 0 ? fn * fn : fsq + fn * fn;
+    }
+    const float flen = sqrtf(fsq);
+    for (int k = 0; k < n; ++k) {
+        no[k] = VO(k) + hit.dist * VD(k);
+        const float u = rec[1 + k] / flen;
+        nd[k] = denom > 0.0f ? -u : u;
+    }
+}
+
+// solid::intersects writing through to the caller's normal ray as the reference does (solid_intersects_marks /
+// cube_local_marks in nt_composite.hpp; tracer.hpp:126-152, 251-276)
+__device__ __noinline__ float solid_marks_var(const VarCtx &cx, int idx, float cutoff, float *no, float *nd) {
+    const int n = cx.n;
+    const float *orient = cx.sc.solid_recs + (size_t)idx * (2 * n * n + n);
+    const float *inv = orient + n * n;
+    const float *pos = inv + n * n;
+    float lo[NT_DEV_MAX_DIM], ld[NT_DEV_MAX_DIM];
+    for (int i = 0; i < n; ++i) {
+        float so = 0.0f, sd = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float m = inv[i * n + k];
+            const float po = m * VO(k), pd = m * VD(k);
+            so = k == 0 ? po : so + po;
+            sd = k == 0 ? pd : sd + pd;
+        }
+        lo[i] = so - pos[i];
+        ld[i] = sd;
+    }
+    float dist = 0.0f;
+    if (cx.sc.solid_types[idx] == 1) {
+        for (int i = 0; i < n; ++i) {
+            const float di = ld[i];
+            if (di == 0.0f) continue;
+            const float s = di < 0.0f ? 1.0f : -1.0f;
+            no[i] = s;
+            const float t = (s - lo[i]) / di;
+            if (!(t > 0.0f)) continue;
+            bool ok = true;
+            for (int j = 0; j < n; ++j) {
+                if (j != i) {
+                    const float p = ld[j] * t + lo[j];
+                    no[j] = p;
+                    if (fabsf(p) > (1.0f + NT_FUZZ)) { ok = false; break; }
+                }
+            }
+            if (!ok) continue;
+            if (t >= cutoff) return 0.0f;
+            dist = t;
+            for (int j = 0; j < n; ++j) nd[j] = j == i ? s : 0.0f;
+            break;
+        }
+    } else {
+        float a = 0.0f, b = 0.0f, c = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float pa = ld[k] * ld[k], pb = ld[k] * lo[k], pc = lo[k] * lo[k];
+            a = k == 0 ? pa : a + pa;
+            b = k == 0 ? pb : b + pb;
+            c = k == 0 ? pc : c + pc;
+        }
+        b = 2.0f * b;
+        c = c - 1.0f;
+        const float disc = b * b - 4.0f * a * c;
+        if (disc < 0.0f) return 0.0f;
+        const float t = (-b - sqrtf(disc)) / (2.0f * a);
+        if (t <= 0.0f || t >= cutoff) return 0.0f;
+        dist = t;
+        for (int j = 0; j < n; ++j) { no[j] = lo[j] + ld[j] * t; nd[j] = no[j]; }
+    }
+    if (dist == 0.0f) return 0.0f;
+    // (lo, ld are done with: they hold the local normal ray while it is turned back to world space)
+    for (int i = 0; i < n; ++i) { lo[i] = no[i] + pos[i]; ld[i] = nd[i]; }
+    for (int i = 0; i < n; ++i) {
+        float so = 0.0f, sd = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float m = orient[i * n + k];
+            const float po = m * lo[k], pd = m * ld[k];
+            so = k == 0 ? po : so + po;
+            sd = k == 0 ? pd : sd + pd;
+        }
+        no[i] = so;
+        nd[i] = sd;
+    }
+    return dist;
+}
+
+__device__ __forceinline__ float test_item_marks_var(const VarCtx &cx, int item, float cutoff, int skip_item, int skip_lane, int &lane_out,
+                                                     float *no, float *nd) {
+    if ((item & 3) == 2) {
+        lane_out = -1;
+        return solid_marks_var(cx, item >> 2, cutoff, no, nd);
+    }
+    const float t = test_item_var(cx, item, cutoff, skip_item, skip_lane, lane_out);
+    if (t != 0.0f) {
+        Hit h;
+        h.dist = t;
+        h.item = item;
+        h.lane = lane_out;
+        hit_normal_var(cx, h, no, nd);
+    }
+    return t;
+}
+
+// leaf_closest_t (nt_composite.hpp): kd_leaf<Store,true>::intersects with transparent hits (tracer.hpp:977-1086)
+template <bool ALIAS>
+__device__ __noinline__ bool leaf_closest_var_t(const VarCtx &cx, int start, int count, int skip_item, int skip_lane, Hit &hit, TList &th,
+                                                const Checked &ck, float *hn_o, float *hn_d, float *nn_o, float *nn_d) {
+    const NtCompositeDev &sc = cx.sc;
+    const int h_start = th.n;
+    bool found = false;
+    float dist_last = 0.0f;
+    for (int i = 0; i < count; ++i) {
+        const int item = sc.items[start + i];
+        if ((item & 3) != 0 && item == skip_item) continue;
+        if (checked_seen(ck, item)) continue;
+        int l;
+        float t;
+        if (ALIAS) {
+            if (!found) {
+                t = test_item_marks_var(cx, item, hit.dist, skip_item, skip_lane, l, hn_o, hn_d);
+            } else {
+                t = test_item_marks_var(cx, item, hit.dist, skip_item, skip_lane, l, nn_o, nn_d);
+                if (t != 0.0f && material_of(sc, item, l)[6] >= 1.0f) {
+                    for (int k = 0; k < cx.n; ++k) { hn_o[k] = nn_o[k]; hn_d[k] = nn_d[k]; }
+                }
+            }
+        } else {
+            t = test_item_var(cx, item, hit.dist, skip_item, skip_lane, l);
+        }
+        dist_last = t;
+        if (t != 0.0f) {
+            if (material_of(sc, item, l)[6] >= 1.0f) {
+                hit.dist = t;
+                hit.item = item;
+                hit.lane = l;
+                if (!found) {
+                    found = true;
+                    dist_last = 0.0f;
+                }
+            } else {
+                tl_add(th, t, item, l);
+            }
+        }
+    }
+    if (found) tl_trim(th, dist_last, h_start);
+    return found;
+}
+
+// trace_closest_t (nt_composite.hpp) for the current ray
+template <bool ALIAS>
+__device__ __noinline__ bool trace_closest_var_t(const VarCtx &cx, float t_near, int skip_item, int skip_lane, Hit &hit, TList &th,
+                                                 const Checked &ck, float *hn_o, float *hn_d, float *nn_o, float *nn_d) {
+    const NtCompositeDev &sc = cx.sc;
+    const WaveLds &w = cx.w;
+    const int lane = cx.lane;
+    hit.dist = FLT_MAX;
+    hit.item = -1;
+    hit.lane = -1;
+    th.n = 0;
+    checked_reset(ck);
+    int node = sc.root, sp = 0, dirty = 0;
+    float t_far = FLT_MAX;
+    const int max_sp = sc.stack_depth;
+    for (;;) {
+        while (node >= 0) {
+            const NtNode nd = sc.nodes[node];
+            if (nd.axis < 0) {
+                if (leaf_closest_var_t<ALIAS>(cx, nd.left, nd.right, skip_item, skip_lane, hit, th, ck, hn_o, hn_d, nn_o, nn_d)) dirty = sp;
+                node = -1;
+                break;
+            }
+            const float2 oi = w.ray[nd.axis * 64 + lane];
+            const float oa = oi.x, inv = oi.y;
+            if (inv == inv) {
+                if (oa == nd.split) { node = inv > 0.0f ? nd.right : nd.left; continue; }
+                const float t = (nd.split - oa) * inv;
+                const bool gt = oa > nd.split;
+                const int n_near = gt ? nd.right : nd.left;
+                const int n_far = gt ? nd.left : nd.right;
+                if (t < 0.0f || t > t_far) { node = n_near; continue; }
+                if (t < t_near) { node = n_far; continue; }
+                if (n_near >= 0) {
+                    if (sp < max_sp) {
+                        w.stack[sp * 64 + lane] = (int)((unsigned)node | ((unsigned)th.n << 24));
+                        ++sp;
+                    }
+                    t_far = t;
+                    node = n_near;
+                    continue;
+                }
+                node = n_far;
+                t_near = t;
+                continue;
+            }
+            node = oa >= nd.split ? nd.right : nd.left;
+        }
+        bool resumed = false;
+        while (sp > 0) {
+            --sp;
+            const unsigned e = (unsigned)w.stack[sp * 64 + lane];
+            const bool improved = sp < dirty;
+            if (dirty > sp) dirty = sp;
+            const int h_start = (int)((e >> 24) & 0x7fu);
+            if (e & NT_STK_MARK) {
+                if (improved) tl_trim(th, hit.dist, h_start);
+                continue;
+            }
+            const NtNode nd = sc.nodes[e & 0xffffffu];
+            bool gt;
+            const float t = branch_t(w, lane, nd, gt);
+            const int far = gt ? nd.left : nd.right;
+            if ((improved && hit.dist <= t) || far < 0) continue;
+            if (improved) {
+                w.stack[sp * 64 + lane] = (int)(e | NT_STK_MARK);
+                ++sp;
+            }
+            node = far;
+            t_near = t;
+            t_far = FLT_MAX;
+            for (int k = (improved ? sp - 2 : sp - 1); k >= 0; --k) {
+                const unsigned ek = (unsigned)w.stack[k * 64 + lane];
+                if (!(ek & NT_STK_MARK)) {
+                    const NtNode up = sc.nodes[ek & 0xffffffu];
+                    bool g2;
+                    t_far = branch_t(w, lane, up, g2);
+                    break;
+                }
+            }
+            resumed = true;
+            break;
+        }
+        if (!resumed) break;
+    }
+    return hit.item >= 0;
+}
+
+// trace_occluded_t (nt_composite.hpp) for the current ray: transparent hits are collected, an opaque one blocks
+__device__ __noinline__ bool trace_occluded_var_t(const VarCtx &cx, float ldistance, int skip_item, int skip_lane, TList &sh) {
+    const NtCompositeDev &sc = cx.sc;
+    const WaveLds &w = cx.w;
+    const int lane = cx.lane;
+    sh.n = 0;
+    int node = sc.root, sp = 0;
+    float t_near = 0.0f, t_far = FLT_MAX;
+    const int max_sp = sc.stack_depth;
+    for (;;) {
+        while (node >= 0) {
+            const NtNode nd = sc.nodes[node];
+            if (nd.axis < 0) {
+                for (int i = 0; i < nd.right; ++i) {
+                    const int item = sc.items[nd.left + i];
+                    if ((item & 3) != 0 && item == skip_item) continue;
+                    int l;
+                    const float t = test_item_var(cx, item, ldistance, skip_item, skip_lane, l);
+                    if (t != 0.0f) {
+                        if (material_of(sc, item, l)[6] >= 1.0f) return true;
+                        tl_add(sh, t, item, l);
+                    }
+                }
+                node = -1;
+                break;
+            }
+            const float2 oi = w.ray[nd.axis * 64 + lane];
+            const float oa = oi.x, inv = oi.y;
+            if (inv == inv) {
+                if (oa == nd.split) { node = inv > 0.0f ? nd.right : nd.left; continue; }
+                const float t = (nd.split - oa) * inv;
+                const bool gt = oa > nd.split;
+                const int n_near = gt ? nd.right : nd.left;
+                const int n_far = gt ? nd.left : nd.right;
+                if (t < 0.0f || t > t_far) { node = n_near; continue; }
+                if (t < t_near) { node = n_far; continue; }
+                if (n_near >= 0) {
+                    if (sp < max_sp) { w.stack[sp * 64 + lane] = node; ++sp; }
+                    t_far = t;
+                    node = n_near;
+                    continue;
+                }
+                if (t < ldistance) { node = -1; break; }
+                t_near = t;
+                node = n_far;
+                continue;
+            }
+            node = oa >= nd.split ? nd.right : nd.left;
+        }
+        bool resumed = false;
+        while (sp > 0) {
+            --sp;
+            const NtNode nd = sc.nodes[w.stack[sp * 64 + lane]];
+            bool gt;
+            const float t = branch_t(w, lane, nd, gt);
+            const int far = gt ? nd.left : nd.right;
+            if (t < ldistance || far < 0) continue;
+            node = far;
+            t_near = t;
+            t_far = FLT_MAX;
+            if (sp > 0) {
+                const NtNode up = sc.nodes[w.stack[(sp - 1) * 64 + lane]];
+                bool g2;
+                t_far = branch_t(w, lane, up, g2);
+            }
+            resumed = true;
+            break;
+        }
+        if (!resumed) return false;
+    }
+}
+
+// light_reaches (tracer.hpp:1750-1766); the shadow ray is the current ray
+__device__ __forceinline__ bool light_reaches_var_t(const VarCtx &cx, float ldistance, int skip_item, int skip_lane, Color3 &filtered) {
+    TList sh;
+    if (trace_occluded_var_t(cx, ldistance, skip_item, skip_lane, sh)) return false;
+    if (sh.n) {
+        tl_sort_unique(sh);
+        for (int i = sh.n - 1; i >= 0; --i) filtered = cscale(filtered, 1.0f - material_of(cx.sc, sh.e[i].item, sh.e[i].lane)[6]);
+    }
+    return true;
+}
+
+// composite_color_t (nt_composite.hpp): ray_color / base_color as a state machine over the frame stack.  On entry the
+// primary ray is the current ray; `nframes` frames are there (max_reflect_depth + 1 when anything reflects).
+template <bool ALIAS>
+__device__ __noinline__ Color3 composite_color_var_t(const VarCtx &cx, const VarFrames &fr, const Checked &ck, int nframes) {
+    const NtCompositeDev &sc = cx.sc;
+    const int n = cx.n;
+    const int S = 4 * n;                  // first scalar word of a frame
+    float a0[NT_DEV_MAX_DIM], a1[NT_DEV_MAX_DIM], a2[NT_DEV_MAX_DIM], a3[NT_DEV_MAX_DIM];
+    for (int k = 0; k < n; ++k) { FRW(0, k) = VO(k); FRW(0, n + k) = VD(k); }
+    FRI(0, S + VF_DEPTH) = 0;
+    FRI(0, S + VF_SKIP_ITEM) = -1;
+    FRI(0, S + VF_SKIP_LANE) = -1;
+    int fp = 0;
+    int state = 0;          // 0: trace the frame's ray, 1: shade its next surface, 2: a reflection has returned
+    Color3 result = c3(0.0f, 0.0f, 0.0f);
+    for (;;) {
+        if (state == 0) {
+            // ---- ray_color: intersect (tracer.hpp:1861-1868); the frame's ray becomes the current ray
+            float *hn_o = a0, *hn_d = a1;
+            for (int k = 0; k < n; ++k) {
+                const float dk = FRW(fp, n + k);
+                cx.L.dv[k * 64 + cx.lane] = dk;
+                cx.L.ray[k * 64 + cx.lane] = make_float2(FRW(fp, k), dk != 0.0f ? 1.0f / dk : __int_as_float(0x7fc00000));
+                hn_o[k] = 0.0f;
+                hn_d[k] = 0.0f;
+            }
+            TList th;
+            th.n = 0;
+            Hit hit;
+            hit.item = -1; hit.lane = -1; hit.dist = FLT_MAX;
+            const float dist = aabb_distance_var(cx);
+            if (dist >= 0.0f)
+                trace_closest_var_t<ALIAS>(cx, dist, FRI(fp, S + VF_SKIP_ITEM), FRI(fp, S + VF_SKIP_LANE), hit, th, ck, hn_o, hn_d, a2, a3);
+            if (ALIAS) {
+                for (int k = 0; k < n; ++k) { FRW(fp, 2 * n + k) = hn_o[k]; FRW(fp, 3 * n + k) = hn_d[k]; }
+            }
+            tl_sort_unique(th);
+            FRW(fp, S + VF_SURF) = hit.dist;
+            FRI(fp, S + VF_SURF + 1) = hit.item;
+            FRI(fp, S + VF_SURF + 2) = hit.lane;
+            for (int i = 0; i < th.n; ++i) {          // farthest first (:1874)
+                const THit e = th.e[th.n - 1 - i];
+                FRW(fp, S + VF_SURF + 3 * (1 + i)) = e.dist;
+                FRI(fp, S + VF_SURF + 3 * (1 + i) + 1) = e.item;
+                FRI(fp, S + VF_SURF + 3 * (1 + i) + 2) = e.lane;
+            }
+            FRI(fp, S + VF_NSURF) = 1 + th.n;
+            FRI(fp, S + VF_J) = 0;
+            fr_put3(fr, fp, S + VF_R, c3(0.0f, 0.0f, 0.0f));
+            state = 1;
+            continue;
+        }
+        const int j = FRI(fp, S + VF_J);
+        Color3 col;
+        float opacity = 1.0f;
+        if (state == 1) {
+            if (j == FRI(fp, S + VF_NSURF)) {
+                // ---- the frame is complete: hand its colour to the waiting base_color, or finish
+                result = fr_get3(fr, fp, S + VF_R);
+                if (fp == 0) break;
+                --fp;
+                state = 2;
+                continue;
+            }
+            Hit hit;
+            hit.dist = FRW(fp, S + VF_SURF + 3 * j);
+            hit.item = FRI(fp, S + VF_SURF + 3 * j + 1);
+            hit.lane = FRI(fp, S + VF_SURF + 3 * j + 2);
+            float *dir = a0, *no = a1, *nd = a2, *lv = a3;
+            for (int k = 0; k < n; ++k) dir[k] = FRW(fp, n + k);
+            if (hit.item < 0) {            // miss: background (only surface 0 can be this)
+                const float iv = dir[sc.bg_axis];
+                fr_put3(fr, fp, S + VF_R, iv >= 0.0f ? cadd(cscale(c3p(sc.bg1), iv), cscale(c3p(sc.bg2), 1.0f - iv))
+                                                     : cadd(cscale(c3p(sc.bg3), -iv), cscale(c3p(sc.bg2), 1.0f + iv)));
+                FRI(fp, S + VF_J) = j + 1;
+                continue;
+            }
+            // ---- base_color (tracer.hpp:1768-1854)
+            if (ALIAS && j == 0) {
+                // the opaque hit is shaded with o_hit.normal as the walk left it (tracer.hpp:1864)
+                for (int k = 0; k < n; ++k) { no[k] = FRW(fp, 2 * n + k); nd[k] = FRW(fp, 3 * n + k); }
+            } else {
+                // (shadow rays and reflections have replaced the current ray since the frame was traced)
+                for (int k = 0; k < n; ++k) {
+                    cx.L.dv[k * 64 + cx.lane] = dir[k];
+                    cx.L.ray[k * 64 + cx.lane].x = FRW(fp, k);
+                }
+                hit_normal_var(cx, hit, no, nd);
+            }
+            const float *m = material_of(sc, hit.item, hit.lane);
+            opacity = m[6];
+            Color3 light = c3(0.0f, 0.0f, 0.0f), specular = c3(0.0f, 0.0f, 0.0f);
+            float spec_a = 0.0f;
+            for (int li = 0; li < sc.n_point_lights; ++li) {
+                const float *pos = sc.pl_pos + (size_t)li * n;
+                const Color3 plc = c3p(sc.pl_color + 3 * li);
+                for (int k = 0; k < n; ++k) lv[k] = no[k] - pos[k];
+                const float ldist = sqrtf(dot_var(n, lv, lv));
+                for (int k = 0; k < n; ++k) lv[k] = lv[k] / ldist;
+                const float sine = dot_var(n, nd, lv);
+                if (sine > 0.0f) {
+                    const float strength = (float)(1.0 / pow((double)ldist, (double)(n - 1)));
+                    if (sc.shadows) {
+                        if (fmaxf(plc.r, fmaxf(plc.g, plc.b)) * strength * sine > NT_LIGHT_THRESHOLD) {
+                            Color3 filtered = plc;
+                            var_set_ray(cx, no, lv);
+                            if (light_reaches_var_t(cx, ldist, hit.item, hit.lane, filtered)) {
+                                filtered = cscale(filtered, strength);
+                                light = cadd(light, cscale(filtered, sine));
+                                if (m[8] != 0.0f) append_specular_var(n, specular, spec_a, m, filtered, dir, nd, lv);
+                            }
+                        }
+                    } else {
+                        light = cadd(light, cscale(cscale(plc, strength), sine));
+                    }
+                }
+            }
+            for (int li = 0; li < sc.n_global_lights; ++li) {
+                const float *gd = sc.gl_dir + (size_t)li * n;
+                const Color3 glc = c3p(sc.gl_color + 3 * li);
+                const float sine = -dot_var(n, nd, gd);
+                if (sine > 0.0f) {
+                    if (sc.shadows) {
+                        for (int k = 0; k < n; ++k) lv[k] = -gd[k];
+                        Color3 filtered = glc;
+                        var_set_ray(cx, no, lv);
+                        if (light_reaches_var_t(cx, FLT_MAX, hit.item, hit.lane, filtered)) {
+                            light = cadd(light, cscale(filtered, sine));
+                            if (m[8] != 0.0f) append_specular_var(n, specular, spec_a, m, filtered, dir, nd, lv);
+                        }
+                    } else {
+                        light = cadd(light, cscale(glc, sine));
+                    }
+                }
+            }
+            const float sine = -dot_var(n, dir, nd);
+            if (sc.camera_light && sine > 0.0f) {
+                light = cadd(light, c3(sine, sine, sine));
+                if (m[8] != 0.0f) {
+                    const float base = powf(sine, m[9]) * m[8];
+                    specular = cadd(specular, cscale(cscale(c3p(m + 3), base), (1.0f - spec_a)));
+                    spec_a += base * (1.0f - spec_a);
+                    specular = cscale(specular, spec_a);
+                }
+            }
+            const Color3 r0 = cadd(c3p(sc.ambient), cmul(c3p(m), light));
+            const int depth = FRI(fp, S + VF_DEPTH);
+            if (m[7] != 0.0f && depth < sc.max_reflect_depth && fp + 1 < nframes) {
+                fr_put3(fr, fp, S + VF_SPEC, specular);
+                FRW(fp, S + VF_SPEC_A) = spec_a;
+                fr_put3(fr, fp, S + VF_R0, r0);
+                fr_put3(fr, fp, S + VF_C, c3p(m));
+                FRW(fp, S + VF_REFL) = m[7];
+                const float f = -2.0f * sine;
+                for (int k = 0; k < n; ++k) { FRW(fp + 1, n + k) = dir[k] - nd[k] * f; FRW(fp + 1, k) = no[k]; }
+                FRI(fp + 1, S + VF_DEPTH) = depth + 1;
+                FRI(fp + 1, S + VF_SKIP_ITEM) = hit.item;
+                FRI(fp + 1, S + VF_SKIP_LANE) = hit.lane;
+                ++fp;
+                state = 0;
+                continue;
+            }
+            col = cadd(specular, cscale(r0, 1.0f - spec_a));
+        } else {
+            // ---- state 2: the reflection of surface j returned `result` (tracer.hpp:1842-1853)
+            const float refl = FRW(fp, S + VF_REFL);
+            const Color3 r = cadd(cscale(cmul(fr_get3(fr, fp, S + VF_C), result), refl), cscale(fr_get3(fr, fp, S + VF_R0), 1.0f - refl));
+            col = cadd(fr_get3(fr, fp, S + VF_SPEC), cscale(r, 1.0f - FRW(fp, S + VF_SPEC_A)));
+            opacity = material_of(sc, FRI(fp, S + VF_SURF + 3 * j + 1), FRI(fp, S + VF_SURF + 3 * j + 2))[6];
+            state = 1;
+        }
+        // ---- ray_color: the opaque hit is the base, transparent hits are blended over it (:1864, :1878)
+        if (j == 0) fr_put3(fr, fp, S + VF_R, col);
+        else fr_put3(fr, fp, S + VF_R, cadd(cscale(col, opacity), cscale(fr_get3(fr, fp, S + VF_R), 1.0f - opacity)));
+        FRI(fp, S + VF_J) = j + 1;
+    }
+    return result;
+}
+
+#undef FRW
+#undef FRI
+
+// The blocks stride over the 8x8-pixel tiles of the launch (the scratch -- `checked` columns and frame stacks -- is sized by
+// the grid, not by the image), one wave per block as in composite_kernel_var.
+template <bool ALIAS>
+__global__ __launch_bounds__(64) void composite_kernel_var_t(NtCamera cam, NtCompositeDev sc, NtTarget tg, int n, int tiles_x, int tiles_y,
+                                                             int frames) {
+    extern __shared__ float2 lds_raw[];
+    const int lane = (int)threadIdx.x;
+    VarLds L;
+    {
+        char *p = reinterpret_cast<char *>(lds_raw);
+        L.ray = reinterpret_cast<float2 *>(p);
+        L.dv = reinterpret_cast<float *>(p + (size_t)64 * n * 8);
+        L.ps = L.dv + (size_t)64 * n;
+        L.stack = reinterpret_cast<int *>(L.ps + (size_t)64 * n);
+        L.mbox = L.stack + (size_t)64 * sc.stack_depth;
+    }
+    WaveLds w;
+    w.ray = L.ray;
+    w.stack = L.stack;
+    w.mbox = L.mbox;
+    const long long slot = (long long)blockIdx.x * 64 + lane;
+    Checked ck;
+    ck.bits = sc.checked + slot;
+    ck.stride = sc.checked_lanes;
+    ck.words = sc.checked_words;
+    ck.n_batches = sc.n_batches;
+    ck.n_triangles = sc.n_triangles;
+    VarFrames fr;
+    fr.base = sc.tframes + slot;
+    fr.stride = sc.checked_lanes;
+    fr.fw = var_frame_words(n);
+    const VarCtx cx = {sc, L, w, n, lane};
+    const long long total = (long long)tiles_x * tiles_y * frames;
+    for (long long tile = (long long)blockIdx.x; tile < total; tile += gridDim.x) {
+        const int bz = (int)(tile / ((long long)tiles_x * tiles_y));
+        const int rem = (int)(tile - (long long)bz * tiles_x * tiles_y);
+        const int by = rem / tiles_x;
+        const int bx = rem - by * tiles_x;
+        const PixelRef pr = tg.colors_out ? locate_pixel_at<8, 8>(tg, bx, by, bz, 0, 0, lane)
+                                          : locate_pixel_at<8, 8>(tg, bx, by, bz, lane & 7, lane >> 3, lane);
+        if (!pr.valid) continue;
+        const float *c = cam.buf ? cam.buf + (size_t)bz * 4 * n : nullptr;
+        // ---- primary ray (tracer.hpp:60-76) becomes the current ray
+        const float sx = tg.fovI * ((float)pr.x - tg.half_w);
+        const float sy = tg.fovI * ((float)pr.y - tg.half_h);
+        float sq = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float rk = c ? c[n + k] : cam.inl[n + k];
+            const float uk = c ? c[2 * n + k] : cam.inl[2 * n + k];
+            const float fk = c ? c[3 * n + k] : cam.inl[3 * n + k];
+            const float v = (fk + rk * sx) - uk * sy;
+            L.dv[k * 64 + lane] = v;
+            sq = k == 0 ? v * v : sq + v * v;
+        }
+        const float len = sqrtf(sq);
+        for (int k = 0; k < n; ++k) {
+            const float dk = L.dv[k * 64 + lane] / len;
+            L.dv[k * 64 + lane] = dk;
+            const float ok_ = c ? c[k] : cam.inl[k];
+            L.ray[k * 64 + lane] = make_float2(ok_, dk != 0.0f ? 1.0f / dk : __int_as_float(0x7fc00000));
+        }
+        const Color3 col = composite_color_var_t<ALIAS>(cx, fr, ck, sc.tframe_count);
+        emit_pixel(tg, pr, col.r, col.g, col.b);
+    }
+}
+
 __global__ __launch_bounds__(64) void composite_kernel_var(NtCamera cam, NtCompositeDev sc, NtTarget tg, int n) {
     extern __shared__ float2 lds_raw[];
     const int lane = (int)threadIdx.x;
@@ -978,8 +1604,38 @@ int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &t
     return finish_launch("box kernel launch");
 }
 
+// words per ray_color frame of composite_kernel_var_t (the host sizes NtCompositeDev::tframes with it)
+int nt_var_frame_words(int n) { return var_frame_words(n); }
+
 int nt_launch_composite(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg) {
     int r;
+    if (sc.tframes) {
+        // transparent materials / the reference's normal handling at run-time n (or beyond the fixed kernels' frame stack)
+        if (li.n < 3 || li.n > NT_DEV_MAX_DIM || !sc.checked || sc.checked_lanes < 64) {
+            snprintf(nt_launch_error_buf(), NT_LAUNCH_ERROR_LEN, "run-time-n transparency kernel: bad launch (n %d)", li.n);
+            return -2;
+        }
+        const size_t lds = (size_t)64 * ((size_t)li.n * 16 + (size_t)sc.stack_depth * 4 + (size_t)NT_MBOX * 4);
+        if (lds > 160 * 1024) {
+            snprintf(nt_launch_error_buf(), NT_LAUNCH_ERROR_LEN, "scene too deep for the LDS budget (n %d, depth %d)", li.n, sc.stack_depth);
+            return -1;
+        }
+        dim3 grid;
+        grid_for(tg, 8, 8, li.nframes, grid);
+        const unsigned blocks = (unsigned)(sc.checked_lanes / 64);
+        if (sc.alias_normals) {
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(composite_kernel_var_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(composite_kernel_var_t<true>, dim3(blocks), dim3(64), lds, (hipStream_t)li.stream, cam, sc, tg, li.n, (int)grid.x,
+                               (int)grid.y, (int)grid.z);
+        } else {
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(composite_kernel_var_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(composite_kernel_var_t<false>, dim3(blocks), dim3(64), lds, (hipStream_t)li.stream, cam, sc, tg, li.n, (int)grid.x,
+                               (int)grid.y, (int)grid.z);
+        }
+        return finish_launch("composite kernel launch");
+    }
     switch (force_var() ? 0 : li.n) {
         case 3: r = nt_composite_fixed_3(li, cam, sc, tg); break;
         case 4: r = nt_composite_fixed_4(li, cam, sc, tg); break;
@@ -1006,6 +1662,8 @@ int nt_launch_composite(const NtLaunchInfo &li, const NtCamera &cam, const NtCom
                 snprintf(nt_launch_error_buf(), NT_LAUNCH_ERROR_LEN, "scene too deep for the LDS budget (n %d, depth %d)", li.n, sc.stack_depth);
                 return -1;
             }
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(composite_kernel_var), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(composite_kernel_var, grid, dim3(64), lds, (hipStream_t)li.stream, cam, sc, tg, li.n);
             r = 0;
         }

@@ -392,10 +392,15 @@ def test_twelve_dimensional_lit_scene_vs_reference_and_oracle():
     assert np.abs(img.view(">f4") - ref.view(">f4")).max() < TOL_ORACLE
 
 
-def test_run_time_n_kernel_has_the_feature_set_of_the_fixed_ones(monkeypatch):
+@pytest.mark.parametrize("clean", [False, True])
+def test_run_time_n_kernel_has_the_feature_set_of_the_fixed_ones(monkeypatch, clean):
     """NTRACER_FORCE_VAR=1 sends the 3-D feature scene (all materials opaque: loose triangles, a Solid cube, two spheres,
-    lights, shadows, reflection to depth 4 / 1 / 0) through composite_kernel_var: the oracle's colours (clean-normal mode)."""
+    lights, shadows, reflection to depth 4 / 1 / 0) through the run-time-n kernels: composite_kernel_var_t<true> (the
+    reference's o_hit.normal handling, as Solids are present) against the default-mode oracle, and with
+    NTRACER_CLEAN_NORMALS=1 composite_kernel_var against the clean-mode one."""
     monkeypatch.setenv("NTRACER_FORCE_VAR", "1")
+    if clean:
+        monkeypatch.setenv("NTRACER_CLEAN_NORMALS", "1")
     g = fx.load("feature3d")
     flat = fx.flat_of(g, opaque=True)
     w, h = int(g["width"]), int(g["height"])
@@ -406,13 +411,144 @@ def test_run_time_n_kernel_has_the_feature_set_of_the_fixed_ones(monkeypatch):
         p = fx.params_of(g, "%s__" % v)
         sc.set_params_flat(p)
         c = sc.colors_at(xs.ravel(), ys.ravel(), w, h)
-        o = ob.OracleScene(3, g["origin"], g["axes"], flat=flat, params=p, clean_normals=True).colors_at(xs.ravel(), ys.ravel(), w, h)
+        o = ob.OracleScene(3, g["origin"], g["axes"], flat=flat, params=p, clean_normals=clean).colors_at(xs.ravel(), ys.ravel(), w, h)
         assert np.abs(c - o).max() < TOL_ORACLE, str(v)
-    # transparent materials stay refused there
-    sct = tracern.CompositeScene.from_flat(3, fx.flat_of(g))
-    sct._set_camera_arrays(g["origin"], g["axes"])
-    with pytest.raises(NotImplementedError):
-        sct.colors_at(xs.ravel()[:64], ys.ravel()[:64], w, h)
+
+
+def test_run_time_n_transparency_kernel_vs_oracle_and_the_fixed_kernel(monkeypatch):
+    """composite_kernel_var_t (transparent-hit lists, trims, compositing, shadow filtering, the exact `checked` list, frames
+    in global scratch) on the scenes the compile-time-N transparency kernel is tested with: feature3d with its transparent
+    materials, every variant, in both normal modes; feature5_n5 against the reference's colours; an image render and a
+    multi-frame launch (blocks striding over the tiles).  The two kernels follow the same operation order: equal colours."""
+    g = fx.load("feature3d")
+    flat = fx.flat_of(g)
+    w, h = int(g["width"]), int(g["height"])
+    ys, xs = np.mgrid[0:h, 0:w]
+    fixed = {}
+    sc = tracern.CompositeScene.from_flat(3, flat)
+    sc._set_camera_arrays(g["origin"], g["axes"])
+    for v in g["variants"]:
+        sc.set_params_flat(fx.params_of(g, "%s__" % v))
+        fixed[str(v)] = sc.colors_at(xs.ravel(), ys.ravel(), w, h)
+    g5 = fx.load("feature5_n5")
+    flat5, p5 = fx.flat_of(g5), fx.params_of(g5)
+    sc5 = tracern.CompositeScene.from_flat(5, flat5)
+    sc5.set_params_flat(p5)
+    sc5._set_camera_arrays(g5["origins"][9], g5["axes"][9])
+    fixed5 = sc5.colors_at(g5["xs"], g5["ys"], 160, 100)
+
+    monkeypatch.setenv("NTRACER_FORCE_VAR", "1")
+    for clean in (False, True):
+        if clean:
+            monkeypatch.setenv("NTRACER_CLEAN_NORMALS", "1")
+        for v in g["variants"]:
+            p = fx.params_of(g, "%s__" % v)
+            sc.set_params_flat(p)
+            c = sc.colors_at(xs.ravel(), ys.ravel(), w, h)
+            o = ob.OracleScene(3, g["origin"], g["axes"], flat=flat, params=p, clean_normals=clean).colors_at(xs.ravel(), ys.ravel(), w, h)
+            assert np.abs(c - o).max() < TOL_ORACLE, (str(v), clean)
+            if not clean:
+                assert np.abs(c - fixed[str(v)]).max() <= 1e-6, str(v)
+    monkeypatch.delenv("NTRACER_CLEAN_NORMALS")
+    c5 = sc5.colors_at(g5["xs"], g5["ys"], 160, 100)
+    assert np.abs(c5 - fixed5).max() <= 1e-6
+    assert np.abs(c5 - g5["colors"][1]).max() < TOL_REF
+    # image renders: one frame through nt_render, three through one device launch
+    img = render_host(sc, fmt_of(w, h, fx.RGB16), strict_reference=True)
+    ref = ob.OracleScene(3, g["origin"], g["axes"], flat=flat, params=p).render(w, h, fx.RGB16, threads=3)
+    assert np.abs(img.astype(int) - ref.astype(int)).max() <= 1
+    import torch
+    fmt = fmt_of(w, h, fx.RGBF32)
+    fb = torch.zeros((3, fmt.pitch * h), dtype=torch.uint8, device="cuda")
+    o3 = np.ascontiguousarray(np.stack([g["origin"]] * 3), np.float32)
+    a3 = np.ascontiguousarray(np.stack([g["axes"]] * 3), np.float32)
+    o3[1, 0] += 0.25
+    o3[2, 1] -= 0.3
+    fst = fmt._as_struct()
+    _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), fmt.pitch * h, 3, o3.ctypes.data_as(_lib.f32p),
+                                                  a3.ctypes.data_as(_lib.f32p), C.byref(fst), None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = fb.cpu().numpy()
+    for k in range(3):
+        ref = ob.OracleScene(3, o3[k], a3[k], flat=flat, params=p).render(w, h, fx.RGBF32, threads=3)
+        assert np.abs(got[k].view(">f4") - ref.reshape(-1).view(">f4")).max() < TOL_ORACLE, k
+
+
+def test_eleven_dimensional_feature_scene_vs_reference(monkeypatch):
+    """feature11_n11, captured from the reference's generic run-time-n module (var_geometry): transparent and reflective
+    simplices, Solids (one transparent), point + global light, shadows, reflection depth 3, in eleven dimensions -- above the
+    compile-time-N kernels, so composite_kernel_var_t<true>.  The reference's colours on every sample (1e-4), the
+    default-mode oracle's to 1e-5; NTRACER_CLEAN_NORMALS=1: the clean-mode oracle's."""
+    g = fx.load("feature11_n11")
+    flat = fx.flat_of(g)
+    p = fx.params_of(g)
+    assert (np.asarray(flat["materials"])[:, 6] < 1).sum() == 2 and len(flat["solid_recs"]) == 2
+    sc = tracern.CompositeScene.from_flat(11, flat)
+    sc.set_params_flat(p)
+    for clean in (False, True):
+        if clean:
+            monkeypatch.setenv("NTRACER_CLEAN_NORMALS", "1")
+        for k, f in enumerate(g["frames"]):
+            sc._set_camera_arrays(g["origins"][f], g["axes"][f])
+            c = sc.colors_at(g["xs"], g["ys"], 160, 100)
+            o = ob.OracleScene(11, g["origins"][f], g["axes"][f], flat=flat, params=p, clean_normals=clean).colors_at(g["xs"], g["ys"], 160, 100)
+            assert np.abs(c - o).max() < TOL_ORACLE, (int(f), clean)
+            if not clean:
+                assert np.abs(c - g["colors"][k]).max() < TOL_REF, int(f)
+    monkeypatch.delenv("NTRACER_CLEAN_NORMALS")
+    sc._set_camera_arrays(g["origins"][9], g["axes"][9])
+    img = render_host(sc, fmt_of(160, 100, fx.RGBF32))
+    ref = ob.OracleScene(11, g["origins"][9], g["axes"][9], flat=flat, params=p).render(160, 100, fx.RGBF32, threads=7)
+    assert np.abs(img.view(">f4") - ref.view(">f4")).max() < TOL_ORACLE
+
+
+def test_reflection_among_transparent_things_to_any_depth():
+    """Two mirrors facing each other with a half-transparent, slightly reflective pane and an opaque triangle between them,
+    max_reflect_depth = 12: beyond the six ray_color frames the compile-time-N transparency kernel keeps, so the launch
+    goes to the run-time-n kernel, whose frame stack the host sizes (the reference recurses to any depth,
+    tracer.hpp:1842-1851).  Against the oracle's plain recursion; the same scene at depth 5 (compile-time-N kernel) differs."""
+    from ntracer_amd import NTracer
+    nt = NTracer(3)
+    mirror = ntracer_amd.Material((0.95, 0.9, 0.85), 1, 0.9, 0.4, 20)
+    pane = ntracer_amd.Material((0.2, 0.5, 1.0), 0.5, 0.3, 0.6, 12)
+    red = ntracer_amd.Material((1, 0.3, 0.2), 1, 0.0)
+    V = nt.Vector
+    protos = []
+    for z, flip in ((1.5, False), (-1.5, True)):
+        quad = [(-300, -300, z), (300, -300, z), (300, 300, z), (-300, 300, z)]
+        if flip:
+            quad = quad[::-1]
+        protos.append(nt.TrianglePrototype([V(*quad[0]), V(*quad[1]), V(*quad[2])], mirror))
+        protos.append(nt.TrianglePrototype([V(*quad[0]), V(*quad[2]), V(*quad[3])], mirror))
+    protos.append(nt.TrianglePrototype([V(-0.4, -0.3, 0.9), V(0.5, -0.3, 0.6), V(0.1, 0.5, 0.8)], red))
+    protos.append(nt.TrianglePrototype([V(-2.0, -1.5, 0.45), V(2.5, -1.2, 0.35), V(0.2, 2.4, 0.5)], pane))
+    sc0 = nt.build_composite_scene(protos)
+    flat = sc0._flat_description()
+    flat["batch_size"] = 4
+    origin = np.array([0.3, 0.2, 0.0], np.float32)
+    axes = np.eye(3, dtype=np.float32)
+    axes[0] = (0.995, 0.0, 0.0998)
+    axes[2] = (-0.0998, 0.0, 0.995)
+    params = dict(fov=0.9, shadows=1, camera_light=1, max_reflect_depth=12, bg_gradient_axis=1, ambient=[.05, .05, .05], bg1=[1, 1, 1],
+                  bg2=[0, 0, 0], bg3=[0, 1, 1], point_light_pos=np.zeros((0, 3)), point_light_color=np.zeros((0, 3)),
+                  global_light_dir=[[0.1, -1.0, 0.2]], global_light_color=[[0.3, 0.3, 0.3]])
+    w, h = 96, 64
+    ys, xs = np.mgrid[0:h, 0:w]
+    o, cnt = ob.OracleScene(3, origin, axes, flat=flat, params=params).colors_at(xs.ravel(), ys.ravel(), w, h, counters=True)
+    assert cnt["rays"] > 8 * w * h                        # (rays that do not end on the opaque triangle go all 12 levels)
+    sc = tracern.CompositeScene.from_flat(3, flat)
+    sc.set_params_flat(params)
+    sc._set_camera_arrays(origin, axes)
+    c = sc.colors_at(xs.ravel(), ys.ravel(), w, h)
+    assert np.abs(c - o).max() < TOL_ORACLE
+    img = render_host(sc, fmt_of(w, h, fx.RGBF32)).view(">f4").reshape(h, w, 3)
+    assert np.abs(img - np.clip(o, 0, 1).reshape(h, w, 3)).max() < TOL_ORACLE
+    params["max_reflect_depth"] = 5
+    sc.set_params_flat(params)
+    c5 = sc.colors_at(xs.ravel(), ys.ravel(), w, h)
+    o5 = ob.OracleScene(3, origin, axes, flat=flat, params=params).colors_at(xs.ravel(), ys.ravel(), w, h)
+    assert np.abs(c5 - o5).max() < TOL_ORACLE
+    assert (np.abs(c5 - c).max(axis=1) > 1e-3).sum() > 0.2 * w * h
 
 
 @pytest.mark.parametrize("name", ["cell600_n4", "cell120_n4", "orthoplex5_n5", "simplex7_n7", "simplex9_n9", "simplex10_n10"])

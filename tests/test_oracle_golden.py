@@ -147,6 +147,21 @@ def test_five_dimensional_feature_scene_matches_the_reference():
     assert differ_clean > 10
 
 
+def test_eleven_dimensional_feature_scene_matches_the_reference():
+    """feature11_n11: the same kind of scene through the reference's generic run-time-n module (var_geometry) -- the
+    default mode agrees with it on every sample in eleven dimensions too."""
+    g = fx.load("feature11_n11")
+    flat = fx.flat_of(g)
+    p = fx.params_of(g)
+    differ_clean = 0
+    for k, f in enumerate(g["frames"]):
+        c = ob.OracleScene(11, g["origins"][f], g["axes"][f], flat=flat, params=p).colors_at(g["xs"], g["ys"], 160, 100)
+        assert np.abs(c - g["colors"][k]).max() < TOL, int(f)
+        cc = ob.OracleScene(11, g["origins"][f], g["axes"][f], flat=flat, params=p, clean_normals=True).colors_at(g["xs"], g["ys"], 160, 100)
+        differ_clean += int((np.abs(cc - g["colors"][k]).max(axis=1) > TOL).sum())
+    assert differ_clean > 0
+
+
 def test_clean_mode_only_differs_where_the_alias_bites():
     g = fx.load("cell600_n4")
     f = g["frames"][1]

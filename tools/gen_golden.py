@@ -570,12 +570,12 @@ def gen_lit12():
           "solids", len(d["solid_recs"]), "hit fraction", float((np.abs(cols[..., 0] - cols[..., 1]) > 1e-6).mean()))
 
 
-def gen_feature5():
-    """A 5-D scene through the reference's tracer5 module with everything the composite path has: facets of a 5-simplex in
-    opaque, reflective, transparent and transparent + reflective materials, a Solid cube and a Solid sphere (one transparent),
-    a point light, a global light, shadows, reflection depth 3.  Built by the reference's own builder."""
+def gen_feature_n(n, name, w=160, h=100, frames=(0, 9, 21, 34), depth=3):
+    """A scene with everything the composite path has, through the reference's tracer<n> module (n = 5) or its generic
+    run-time-n one (n = 11): facets of an n-simplex in opaque, reflective, transparent and transparent + reflective
+    materials, a cloud of small simplices, a Solid cube and a Solid sphere (one transparent), a point light, a global light,
+    shadows, reflection.  Built by the reference's own builder."""
     import random
-    n = 5
     nt = NTracer(n)
     V = nt.Vector
     mats = [Material((1, 0.5, 0.5)), Material((0.3, 0.8, 0.4), 1, 0.3, 0.7, 10, (1, 1, 0.7)), Material((0.3, 0.4, 1.0), 0.5, 0, 1, 8),
@@ -594,21 +594,25 @@ def gen_feature5():
         c = [rnd.uniform(-2.5, 2.5) for _ in range(n)]
         protos.append(nt.TrianglePrototype([V(*[c[k] + rnd.uniform(-0.8, 0.8) for k in range(n)]) for _ in range(n)], mats[i % 5]))
     ax = lambda i: V.axis(i, 1)
+    pad = [0.0] * (n - 5)
     rot = nt.Matrix.rotation(ax(0), ax(1), 0.4) * nt.Matrix.rotation(ax(2), ax(4), 0.3) * nt.Matrix.scale(0.8)
-    protos.append(nt.SolidPrototype(W.CUBE, V(2.3, -1.0, 0.4, 0.1, -0.2), rot, mats[4]))
-    protos.append(nt.SolidPrototype(W.SPHERE, V(-2.1, 1.3, -0.3, 0.2, 0.0), nt.Matrix.scale(0.9), mats[3]))
+    protos.append(nt.SolidPrototype(W.CUBE, V(2.3, -1.0, 0.4, 0.1, -0.2, *pad), rot, mats[4]))
+    protos.append(nt.SolidPrototype(W.SPHERE, V(-2.1, 1.3, -0.3, 0.2, 0.0, *pad), nt.Matrix.scale(0.9), mats[3]))
     scene = nt.build_composite_scene(protos)
-    scene.add_light(nt.PointLight(V(5.0, 6.0, -7.0, 2.0, 1.0), (3e4, 2.8e4, 2.5e4)))
-    scene.add_light(nt.GlobalLight(V(0.2, -0.9, 0.3, 0.1, 0.05).unit(), (0.4, 0.4, 0.5)))
+    # (a point light's strength falls with distance^(n-1): its colour is scaled so that it matters at this distance)
+    ppos = [5.0, 6.0, -7.0, 2.0, 1.0] + pad
+    pd = math.sqrt(sum(v * v for v in ppos))
+    k = 2.27 * pd ** (n - 1)
+    scene.add_light(nt.PointLight(V(*ppos), (k, 0.93 * k, 0.83 * k)))
+    scene.add_light(nt.GlobalLight(V(0.2, -0.9, 0.3, 0.1, 0.05, *pad).unit(), (0.4, 0.4, 0.5)))
     scene.set_ambient_color((0.03, 0.03, 0.04))
     scene.set_shadows(True)
-    scene.set_max_reflect_depth(3)
+    scene.set_max_reflect_depth(depth)
     fl = Flattener(nt)
     d = fl.arrays(scene)
     cam_distance = -2.2 * 4
     origins, axes = rotation_cameras(nt, cam_distance, frames=40)
-    w, h = 160, 100
-    frames = [0, 9, 21, 34]
+    frames = list(frames)
     xs, ys = lattice(w, h, 2, 2, 1, 0)
     cols = np.zeros((len(frames), len(xs), 3), np.float32)
     for k, f in enumerate(frames):
@@ -617,8 +621,8 @@ def gen_feature5():
     d.update(scene_params(scene))
     d.update(origins=origins, axes=axes, cam_distance=np.float32(cam_distance), frames=np.array(frames, np.int32),
              xs=xs, ys=ys, colors=cols, width=np.int32(w), height=np.int32(h))
-    np.savez_compressed(os.path.join(OUT, "feature5_n5.npz"), **d)
-    print("wrote feature5_n5 nodes", len(d["node_axis"]), "items", len(d["items"]), "batches", len(d["batch_recs"]), "tris", len(d["tri_recs"]),
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, "nodes", len(d["node_axis"]), "items", len(d["items"]), "batches", len(d["batch_recs"]), "tris", len(d["tri_recs"]),
           "solids", len(d["solid_recs"]), "hit fraction", float((np.abs(cols[..., 0] - cols[..., 1]) > 1e-6).mean()))
 
 
@@ -643,7 +647,9 @@ if __name__ == "__main__":
         "simplex7": lambda: gen_polytope("simplex7_n7", ["3"] * 6, 320, 200, [0, 9, 47, 120], (5, 3)),
         "simplex9": lambda: gen_polytope("simplex9_n9", ["3"] * 8, 320, 200, [0, 9, 47, 120], (5, 3)),
         "lit12": gen_lit12,
-        "feature5": gen_feature5,
+        # (feature5_n5 was captured with the point light (3e4, 2.8e4, 2.5e4); regenerating it changes that light a little)
+        "feature5": lambda: gen_feature_n(5, "feature5_n5"),
+        "feature11": lambda: gen_feature_n(11, "feature11_n11", frames=(0, 9, 21)),
     }
     for k, f in jobs.items():
         if a.only is None or k in a.only:
