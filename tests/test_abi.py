@@ -128,14 +128,13 @@ def test_render_argument_checks_come_before_the_device():
         ntracer_amd.BlockingRenderer().render(bytearray(64), fmt, object())
 
 
-def test_unsupported_features_are_refused_not_approximated():
-    g = fx.load("feature3d")
-    sc = tracern.CompositeScene.from_flat(3, fx.flat_of(g))       # transparent AND reflective materials
-    sc.set_max_reflect_depth(6)                                   # needs 7 ray_color frames; the kernel keeps 6
-    fmt = ntracer_amd.ImageFormat(8, 8, [ntracer_amd.Channel(8, 1, 0, 0)])
-    with pytest.raises(NotImplementedError, match="max_reflect_depth"):
-        ntracer_amd.BlockingRenderer().render(bytearray(64), fmt, sc)
-    g = fx.load("box_n10_4096x4096")
+def test_limits_are_refused_not_approximated():
+    """What the library cannot do it refuses: dimensions outside 3..64, records that do not match the dimension.  (Round 2:
+    transparency at any n and any max_reflect_depth are no longer among them -- tests/test_gpu_parity.py.)"""
+    with pytest.raises(ValueError, match="dimension"):
+        tracern.BoxScene(65)
+    with pytest.raises(ValueError, match="dimension"):
+        tracern.BoxScene(2)
     flat = fx.flat_of(fx.load("cell600_n4"))
     with pytest.raises(ValueError):
         tracern.CompositeScene.from_flat(9, flat)                 # record sizes do not match dimension 9
