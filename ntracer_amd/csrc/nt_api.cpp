@@ -69,6 +69,13 @@ struct ChanTable {
     NtChanDev *dev = nullptr;
 };
 
+// NtTarget::rowtab: what the BoxScene tile kernel needs to know about a row, per owned row of one (view, band split, pitch)
+struct RowTable {
+    int height = 0, pitch = 0, rank = 0, world = 1, rows = 0, compact = 0;
+    uint32_t half_h = 0, fovI = 0;       // float bits
+    void *dev = nullptr;
+};
+
 // everything a scene keeps on one HIP device
 struct DeviceState {
     int device = -1;
@@ -93,6 +100,7 @@ struct DeviceState {
     std::vector<std::unique_ptr<TileOrder>> tile_orders;   // packet kernel: tiles sorted centre-out, per tile grid
     int cu_count = 0;
     std::vector<std::unique_ptr<ChanTable>> chan_tables;
+    std::vector<std::unique_ptr<RowTable>> row_tables;
 };
 
 struct Format {                          // validated image_format (render.cpp:167-172)
@@ -356,6 +364,51 @@ int chan_table(DeviceState *ds, const Format &f, const NtChanDev *&dev_ptr) {
     if (!f.chans.empty()) HIP_TRY(hipMemcpy(p, f.chans.data(), f.chans.size() * sizeof(NtChanDev), hipMemcpyHostToDevice));
     dev_ptr = t->dev;
     ds->chan_tables.push_back(std::move(t));
+    return NT_OK;
+}
+
+// The row table of a launch geometry (cached: a render loop keeps its view, band split and pitch).  Entry i belongs to owned
+// row i: sy exactly as the ray source computes it (tracer.hpp:72-74: fovI * (y - half_h), two fp32 operations), whether
+// the row exists, and where it starts in a frame; 64 entries of padding, as a wave reads its sixteen rows unclamped.
+int row_table(DeviceState *ds, const NtTarget &tg, const void *&dev_ptr) {
+    uint32_t hh, fi;
+    std::memcpy(&hh, &tg.half_h, 4);
+    std::memcpy(&fi, &tg.fovI, 4);
+    const int world = std::max(tg.band_world, 1);
+    for (auto &t : ds->row_tables) {
+        if (t->height == tg.height && t->pitch == tg.pitch && t->rank == tg.band_rank && t->world == world && t->rows == tg.band_rows &&
+            t->compact == tg.compact && t->half_h == hh && t->fovI == fi) {
+            dev_ptr = t->dev;
+            return NT_OK;
+        }
+    }
+    struct Entry { float sy; uint32_t valid; long long off; };
+    static_assert(sizeof(Entry) == 16, "16-byte row entries");
+    std::vector<Entry> host;
+    const int rows = std::max(tg.band_rows, 1);
+    for (int orow = 0;; ++orow) {
+        const int band = orow / rows;
+        const int y = world > 1 ? (band * world + tg.band_rank) * rows + (orow - band * rows) : orow;
+        if ((world > 1 ? (band * world + tg.band_rank) * rows : orow) >= tg.height) break;
+        Entry e;
+        e.sy = tg.fovI * ((float)y - tg.half_h);
+        e.valid = y < tg.height ? 1u : 0u;
+        e.off = (long long)(tg.compact ? orow : y) * tg.pitch;
+        host.push_back(e);
+    }
+    for (int k = 0; k < 64; ++k) host.push_back(Entry{0.0f, 0u, 0});
+    if (ds->row_tables.size() >= 8) {                       // a handful of geometries at a time
+        (void)hipDeviceSynchronize();                       // (nothing in flight may still read the one that goes)
+        if (ds->row_tables.front()->dev) (void)hipFree(ds->row_tables.front()->dev);
+        ds->row_tables.erase(ds->row_tables.begin());
+    }
+    auto t = std::make_unique<RowTable>();
+    t->height = tg.height; t->pitch = tg.pitch; t->rank = tg.band_rank; t->world = world; t->rows = tg.band_rows; t->compact = tg.compact;
+    t->half_h = hh; t->fovI = fi;
+    HIP_TRY(hipMalloc(&t->dev, host.size() * sizeof(Entry)));
+    HIP_TRY(hipMemcpy(t->dev, host.data(), host.size() * sizeof(Entry), hipMemcpyHostToDevice));
+    dev_ptr = t->dev;
+    ds->row_tables.push_back(std::move(t));
     return NT_OK;
 }
 
@@ -691,6 +744,9 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             }
             li.cull_clean = fused ? 1 : 0;
             li.cull_buf = (uint32_t *)ds->cull.p;
+            if (fused) {
+                if (int e = row_table(ds, tg, tg.rowtab)) return e;
+            }
         }
         r = nt_launch_box(li, cam, tg);
     }
@@ -869,6 +925,7 @@ void nt_scene_destroy(nt_scene_t *s) {
                           &ds->probes, &ds->stats, &ds->hits, &ds->numer, &ds->cull, &ds->checked, &ds->tframes})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
+        for (auto &t : ds->row_tables) if (t->dev) (void)hipFree(t->dev);
         for (auto &t : ds->tile_orders) t->buf.release();
         for (auto &st : ds->stage) {
             if (st.host) (void)hipHostFree(st.host);

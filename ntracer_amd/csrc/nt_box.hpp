@@ -3,6 +3,7 @@
 // fused with process_pixel's conversion and packing (nt_pixel.hpp), so the only HBM traffic of a frame is the packed
 // framebuffer.  Instantiated per N by nt_inst_box.hip.
 #pragma once
+#include <type_traits>
 #include "nt_pixel.hpp"
 
 namespace {
@@ -230,10 +231,21 @@ __device__ __forceinline__ void box_resolve(const float (&o)[N], const float (&v
     }
 }
 
+// a pointer into global memory every lane agrees on, pinned to scalar registers (and so kept apart from the per-lane
+// offset added to it): base of a global_store with an SGPR address
+typedef __attribute__((address_space(1))) uint8_t *nt_gptr;
+__device__ __forceinline__ nt_gptr uniform_ptr(uint8_t *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (nt_gptr)(((unsigned long long)hi << 32) | lo);
+}
+#define NT_G32(p) (*(__attribute__((address_space(1))) uint32_t *)(p))
+
 // Three fp32 channels that are plain components (tg.plain_f32, 12-byte pixels on 4-byte-aligned rows), BoxScene colours
 // (g == b): the bytes emit_pixel writes for this layout -- clamp, big-endian floats or the reversed pixel -- as one
 // 12-byte store.
-__device__ __forceinline__ void emit_f32x3(const NtTarget &tg, long long offset, float r, float gb) {
+template <typename P>
+__device__ __forceinline__ void emit_f32x3_at(const NtTarget &tg, P p, float r, float gb) {
     r = r > 0.0f ? r : 0.0f;          // simd::clamp, as in channel_value
     r = r < 1.0f ? r : 1.0f;
     gb = gb > 0.0f ? gb : 0.0f;
@@ -250,8 +262,16 @@ __device__ __forceinline__ void emit_f32x3(const NtTarget &tg, long long offset,
         w.y = tg.plain_f32[1] == 0 ? vr : vgb;
         w.z = tg.plain_f32[tg.reversed ? 0 : 2] == 0 ? vr : vgb;
     }
-    *reinterpret_cast<uint3 *>(tg.dest + offset) = w;
+    if constexpr (std::is_same<P, nt_gptr>::value) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        u32x3 v;
+        v.x = w.x; v.y = w.y; v.z = w.z;
+        *(__attribute__((address_space(1))) u32x3 *)(p) = v;
+    } else {
+        *reinterpret_cast<uint3 *>(p) = w;
+    }
 }
+__device__ __forceinline__ void emit_f32x3(const NtTarget &tg, long long offset, float r, float gb) { emit_f32x3_at(tg, tg.dest + offset, r, gb); }
 
 // sqrtf(x) for x in [2^-96, 2^96): hipcc's correctly rounded square root is v_sqrt_f32 followed by a choice among the
 // result and its two neighbours (two fma residuals), wrapped in a rescaling for x < 2^-96 and a pass-through for 0 and
@@ -844,8 +864,8 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
     if (row0 < tg.row_count) {
         unsigned long long rowcodes = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[2 * wv + 1]) << 32) |
                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[2 * wv]);
-        // Row bookkeeping once per wave, one row per lane (lane l <-> row row0 + l), read back with v_readlane; every
-        // lane stays active -- lanes past the right edge redo the last pixel (same bytes, same value) instead of leaving
+        // Which of the wave's rows exist: one row per lane (lane l <-> row row0 + l).  Every lane stays active in the row
+        // loops -- lanes past the right edge redo the last pixel (same bytes, same value) instead of leaving
         const int lorow = tg.row_begin + row0 + lane;
         int ly = lorow;
         if (tg.band_world > 1) {
@@ -853,19 +873,26 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             ly = (band * tg.band_world + tg.band_rank) * tg.band_rows + (lorow - band * tg.band_rows);
         }
         const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < R && row0 + lane < tg.row_count && ly < tg.height);
-        const float v_sy = tg.fovI * ((float)ly - tg.half_h);
-        // byte offset of row rr: scalar arithmetic when the rows of the wave lie `pitch` apart in the buffer (always, unless
-        // rows dealt in bands go to a full-size frame), otherwise read back from a per-lane table like sy
-        const bool rows_linear = tg.band_world <= 1 || tg.compact;
-        const long long wave_off = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.row_begin + row0) * tg.pitch;
-        const long long v_off = (long long)blockIdx.z * tg.frame_stride + (long long)(tg.compact ? lorow : ly) * tg.pitch;
-        const int v_off_lo = (int)v_off, v_off_hi = (int)(v_off >> 32);
-#define NT_ROW_OFF(rr)                                                                                                      \
-        ((rows_linear ? wave_off + (long long)(rr) * tg.pitch                                                                \
-                      : (((long long)__builtin_amdgcn_readlane(v_off_hi, (rr)) << 32) | (unsigned)__builtin_amdgcn_readlane(v_off_lo, (rr)))) + xoff)
+        // What a row loop needs to know about its row -- sy of the ray source and the row's byte offset in a frame -- comes
+        // from a table the host wrote (NtTarget::rowtab, 16 bytes per owned row: sy, -, offset), read through the scalar
+        // data cache (constant address space: s_load_dwordx4): no vector instruction, nothing per lane
+        typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(4))) const nt_u32x4 *nt_rowtab;
+        const nt_rowtab tab = (nt_rowtab)tg.rowtab + (tg.row_begin + row0);
+        uint8_t *const frame_base = tg.dest + (long long)blockIdx.z * tg.frame_stride;
+#define NT_ROW_LOAD(rr)                     \
+        const nt_u32x4 row_e = tab[(rr)];   \
+        const float sy = __uint_as_float(row_e.x)
+#define NT_ROW_OFF() ((long long)(((unsigned long long)row_e.w << 32) | row_e.z) + (long long)blockIdx.z * tg.frame_stride)
+        // a store goes to (row pointer: scalar registers) + (the lane's byte offset in the row: 32 bits) -- the addressing
+        // mode of global_store with an SGPR base, no vector arithmetic on addresses
+#define NT_ROW_PTR() uniform_ptr(frame_base + (long long)(((unsigned long long)row_e.w << 32) | row_e.z))
+        // (instruction selection works block by block and only recognises base + zero-extended 32-bit offset when it sees the
+        // extension: the empty asm keeps it from being hoisted out of the row loops)
+#define NT_LANE_OFF() ({ asm volatile("" : "+v"(xoff)); xoff; })
         int x = (int)blockIdx.x * 64 + lane;
         x = x < tg.width ? x : tg.width - 1;
-        const long long xoff = (long long)x * tg.bpp;
+        uint32_t xoff = (uint32_t)x * (uint32_t)tg.bpp;
         const float sx = tg.fovI * ((float)x - tg.half_w);
         float base[N];
 #pragma unroll
@@ -887,14 +914,12 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 skip &= skip - 1ull;
             }
         }
-        // up[K]*sy of the lane's row, K = its face if the row is one face throughout
-        float v_usK;
-        {
-            const uint32_t lk = ((uint32_t)(rowcodes >> (4 * (lane & 15))) & 15u) - 1u;
-            float upK = up[0];
+        // `up` in vector registers: up[j] * sy has the scalar sy as its one scalar operand
+        float upv[N];
 #pragma unroll
-            for (int j = 1; j < N; ++j) upK = lk == (uint32_t)j ? up[j] : upK;
-            v_usK = upK * v_sy;
+        for (int j = 0; j < N; ++j) {
+            upv[j] = up[j];
+            asm volatile("" : "+v"(upv[j]));
         }
         if (!F32) {
             // ---- packed RGB: guarded rsq quantisation (see box_kernel<N, true>)
@@ -916,8 +941,8 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             while (quick != 0ull) {
                 const int rr = __builtin_ctzll(quick) >> 2;
                 quick &= quick - 1ull;
-                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
-                const float d0 = base[0] - up[0] * sy;                    // dir[0], bit for bit
+                NT_ROW_LOAD(rr);
+                const float d0 = base[0] - upv[0] * sy;                   // dir[0], bit for bit
                 const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
                 const float t = (fabsf(d0) * __builtin_amdgcn_rsqf(sqa)) * maxv;
                 const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);
@@ -925,40 +950,46 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                     todo |= 1ull << (4 * rr);                                     // a lane too close to a rounding boundary
                     continue;
                 }
-                PixelRef pr;
-                pr.offset = NT_ROW_OFF(rr);
+                const nt_gptr out = NT_ROW_PTR() + NT_LANE_OFF();
                 if (tg.plain_sel != 0u) {
                     // 8-bit fields: t + 2^23 has round(t) in its low mantissa byte (t < 255.5; the guard keeps t off the
                     // half-way points, so nearest-even is the reference's rounding), which is the byte v_perm_b32 picks
                     const uint32_t q = __float_as_uint(t + 8388608.0f);
-                    *reinterpret_cast<uint32_t *>(tg.dest + pr.offset) = __builtin_amdgcn_perm(d0 > 0.0f ? q : 0u, q, tg.plain_sel);
+                    NT_G32(out) = __builtin_amdgcn_perm(d0 > 0.0f ? q : 0u, q, tg.plain_sel);
                     continue;
                 }
                 uint32_t q = (uint32_t)(t + 0.5f);
                 q = q < tg.plain_maxval ? q : tg.plain_maxval;
-                emit_plain(tg, pr, d0 > 0.0f ? q : 0u, q);
+                const uint32_t w = (d0 > 0.0f ? q : 0u) * tg.plain_mul[0] + q * (tg.plain_mul[1] + tg.plain_mul[2]);      // (emit_plain)
+                NT_G32(out) = tg.reversed ? w : bswap32(w);
             }
             // (the one-face rows of a wave mostly share their face: its component of `base` is picked once)
             uint32_t K0 = 0u;
-            float bK0 = base[0];
+            float bK0 = base[0], uK0 = upv[0];
             if (inner != 0ull) {
                 K0 = ((uint32_t)(rowcodes >> (__builtin_ctzll(inner) & 60)) & 15u) - 1u;
 #pragma unroll
-                for (int j = 1; j < N; ++j) bK0 = K0 == (uint32_t)j ? base[j] : bK0;
+                for (int j = 1; j < N; ++j) {
+                    bK0 = K0 == (uint32_t)j ? base[j] : bK0;
+                    uK0 = K0 == (uint32_t)j ? upv[j] : uK0;
+                }
             }
             while (inner != 0ull) {
                 const int rr = __builtin_ctzll(inner) >> 2;
                 inner &= inner - 1ull;
                 const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
-                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
-                const float usK = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_usK), rr));
-                float bK = bK0;
+                NT_ROW_LOAD(rr);
+                float bK = bK0, uK = uK0;
                 if (K != K0) {
                     bK = base[0];
+                    uK = upv[0];
 #pragma unroll
-                    for (int j = 1; j < N; ++j) bK = K == (uint32_t)j ? base[j] : bK;
+                    for (int j = 1; j < N; ++j) {
+                        bK = K == (uint32_t)j ? base[j] : bK;
+                        uK = K == (uint32_t)j ? upv[j] : uK;
+                    }
                 }
-                const float dK = bK - usK;                                // dir[K], bit for bit
+                const float dK = bK - uK * sy;                            // dir[K], bit for bit
                 const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
                 const float t = (fabsf(dK) * __builtin_amdgcn_rsqf(sqa)) * maxv, th = t * 0.5f;
                 const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f) &&
@@ -967,17 +998,16 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                     todo |= 1ull << (4 * rr);
                     continue;
                 }
-                PixelRef pr;
-                pr.offset = NT_ROW_OFF(rr);
+                const nt_gptr out = NT_ROW_PTR() + NT_LANE_OFF();
                 if (tg.plain_sel != 0u) {
-                    *reinterpret_cast<uint32_t *>(tg.dest + pr.offset) =
-                        __builtin_amdgcn_perm(__float_as_uint(t + 8388608.0f), __float_as_uint(th + 8388608.0f), tg.plain_sel);
+                    NT_G32(out) = __builtin_amdgcn_perm(__float_as_uint(t + 8388608.0f), __float_as_uint(th + 8388608.0f), tg.plain_sel);
                     continue;
                 }
                 uint32_t qr = (uint32_t)(t + 0.5f), qgb = (uint32_t)(th + 0.5f);
                 qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
                 qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;
-                emit_plain(tg, pr, qr, qgb);
+                const uint32_t w = qr * tg.plain_mul[0] + qgb * (tg.plain_mul[1] + tg.plain_mul[2]);
+                NT_G32(out) = tg.reversed ? w : bswap32(w);
             }
         } else {
             // ---- fp32 channels: the stored value IS x / sqrtf(sq), so the reference's sum, square root and division are
@@ -986,69 +1016,76 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 // background rows: i = dir[0]; i > 0 ? (i,i,i) : (0,-i,-i) (tracer.hpp:109-113), clamped as channel_value does
                 const int rr = __builtin_ctzll(quick) >> 2;
                 quick &= quick - 1ull;
-                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+                NT_ROW_LOAD(rr);
 #pragma unroll
-                for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+                for (int j = 0; j < N; ++j) dir[j] = base[j] - upv[j] * sy;
                 float sq = dir[0] * dir[0];
 #pragma unroll
                 for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
                 const float in = dir[0] / sqrt_wave(sq);
                 float r, gb, b_;
                 box_background(in, r, gb, b_);
-                const long long off = NT_ROW_OFF(rr);
-                emit_f32x3(tg, off, r, gb);
+                emit_f32x3_at(tg, NT_ROW_PTR() + NT_LANE_OFF(), r, gb);
             }
             uint32_t K0 = 0u;
-            float bK0 = base[0];
+            float bK0 = base[0], uK0 = upv[0];
             if (inner != 0ull) {
                 K0 = ((uint32_t)(rowcodes >> (__builtin_ctzll(inner) & 60)) & 15u) - 1u;
 #pragma unroll
-                for (int j = 1; j < N; ++j) bK0 = K0 == (uint32_t)j ? base[j] : bK0;
+                for (int j = 1; j < N; ++j) {
+                    bK0 = K0 == (uint32_t)j ? base[j] : bK0;
+                    uK0 = K0 == (uint32_t)j ? upv[j] : uK0;
+                }
             }
             while (inner != 0ull) {
                 // one face K throughout: sine = d_K * (-sign d_K) <= 0, shade = -sine (tracer.hpp:105-107)
                 const int rr = __builtin_ctzll(inner) >> 2;
                 inner &= inner - 1ull;
                 const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
-                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
-                const float usK = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_usK), rr));
+                NT_ROW_LOAD(rr);
 #pragma unroll
-                for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+                for (int j = 0; j < N; ++j) dir[j] = base[j] - upv[j] * sy;
                 float sq = dir[0] * dir[0];
 #pragma unroll
                 for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-                float bK = bK0;
+                float bK = bK0, uK = uK0;
                 if (K != K0) {
                     bK = base[0];
+                    uK = upv[0];
 #pragma unroll
-                    for (int j = 1; j < N; ++j) bK = K == (uint32_t)j ? base[j] : bK;
+                    for (int j = 1; j < N; ++j) {
+                        bK = K == (uint32_t)j ? base[j] : bK;
+                        uK = K == (uint32_t)j ? upv[j] : uK;
+                    }
                 }
-                const float xk = bK - usK;                                // dir[K], bit for bit (the same two operations)
+                const float xk = bK - uK * sy;                            // dir[K], bit for bit (the same two operations)
                 const float shade = fabsf(xk / sqrt_wave(sq));
-                const long long off = NT_ROW_OFF(rr);
-                emit_f32x3(tg, off, shade * 1.0f, shade * 0.5f);
+                emit_f32x3_at(tg, NT_ROW_PTR() + NT_LANE_OFF(), shade * 1.0f, shade * 0.5f);
             }
         }
         while (todo != 0ull) {
             const int rr = __builtin_ctzll(todo) >> 2;
             todo &= todo - 1ull;
             const bool rowhit = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) != 0u;
-            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_sy), rr));
+            NT_ROW_LOAD(rr);
             PixelRef pr;
             pr.x = x;
             pr.y = 0;
-            pr.offset = NT_ROW_OFF(rr);
+            pr.offset = NT_ROW_OFF() + (long long)xoff;
             pr.hit_index = 0;
             pr.valid = true;
 #pragma unroll
-            for (int j = 0; j < N; ++j) dir[j] = base[j] - up[j] * sy;
+            for (int j = 0; j < N; ++j) dir[j] = base[j] - upv[j] * sy;
             float sq = dir[0] * dir[0];
 #pragma unroll
             for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
             if (!box_pixel<N, !F32, true, false, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit)) redo_bits |= 1u << rr;
         }
     }
+#undef NT_ROW_LOAD
 #undef NT_ROW_OFF
+#undef NT_ROW_PTR
+#undef NT_LANE_OFF
     // mark the rows left over in the redo bitmap (clean on entry: box_redo_kernel zeroes what it has read)
     if (lane == 0) {
         while (redo_bits != 0u) {
@@ -1077,7 +1114,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     // a channel in one aligned dword, and three plain fp32 channels
     const bool fmt_rgb = tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4;
     const bool fmt_f32 = tg.plain_f32[0] >= 0 && tg.bpp == 12 && tg.aligned4;
-    if (li.cull_buf && !tg.colors_out && BoxRows<N>::value > 1 && (fmt_rgb || fmt_f32) && li.box_path != 0 && li.cull_clean) {
+    if (li.cull_buf && tg.rowtab && !tg.colors_out && BoxRows<N>::value > 1 && (fmt_rgb || fmt_f32) && li.box_path != 0 && li.cull_clean) {
         hipStream_t st = (hipStream_t)li.stream;
         // sixteen rows a lane once there are waves to spare (the per-wave set-up is a fifth of the work at eight) -- unless
         // tiles of 64 rows would hang much further over the bottom of the launch than tiles of 32

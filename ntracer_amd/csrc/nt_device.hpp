@@ -63,6 +63,9 @@ struct NtTarget {
     // box_redo_kernel (a lane needed the reference's own face-by-face arithmetic); cleared by box_cull_kernel
     uint32_t *redo;
     int redo_words;
+    // BoxScene tile kernel: per owned row (index = owned-row number; 64 entries of padding) 16 bytes {float sy = fovI*(y -
+    // half_h); uint32 y < height; int64 byte offset of the row within a frame}, read with scalar loads; or nullptr
+    const void *rowtab;
 };
 
 // Camera rows used by the ray source (camera.hpp:40-45): origin, right, up, forward.
