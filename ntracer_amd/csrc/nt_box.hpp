@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
 // of the launch (a rank's 136 rows of a 1080-row frame: three tiles of 48 rows instead of three of 64).
 template <int N, bool F32, int ROWS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
-    static_assert(ROWS == 8 || ROWS == 16, "sixteen row codes to a qword");
+    static_assert(ROWS == 8 || ROWS == 16 || ROWS == 32, "sixteen row codes to a qword, one or two qwords a wave");
     static_assert(WAVES >= 2 && WAVES <= 4, "two to four waves a block");
     constexpr int R = ROWS;
     __shared__ uint32_t s_code[64];
@@ -846,40 +846,30 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             }
             if (y < tg.height) code = box_stretch_code<N>(org, right, up, fwd, tg, y, (int)blockIdx.x);
         }
-        // rows of wave w in nibbles of s_code[2w] (rows 0..7) and s_code[2w + 1] (rows 8..15)
+        // rows of wave w in nibbles of s_code[2w] (rows 0..7) and s_code[2w + 1] (rows 8..15); R == 32: s_code[4w .. 4w + 3]
         uint32_t packed = code << (4 * (lane & 7));
         packed |= (uint32_t)__shfl_xor((int)packed, 1, 64);
         packed |= (uint32_t)__shfl_xor((int)packed, 2, 64);
         packed |= (uint32_t)__shfl_xor((int)packed, 4, 64);
         if ((lane & 7) == 0) {
             const int grp = lane >> 3;                                   // eight rows each
-            const int slot = R == 16 ? grp : 2 * grp;                    // R == 8: wave w's rows are group w
+            const int slot = R == 8 ? 2 * grp : grp;                     // R == 8: wave w's rows are group w
             s_code[slot] = packed;
             if (R == 8) s_code[slot + 1] = 0u;
         }
     }
     __syncthreads();
-    const int row0 = tile_row0 + wv * R;
-    uint32_t redo_bits = 0u;                              // rows (bit rr) left to box_redo_kernel
-    if (row0 < tg.row_count) {
-        unsigned long long rowcodes = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[2 * wv + 1]) << 32) |
-                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[2 * wv]);
-        // Which of the wave's rows exist: one row per lane (lane l <-> row row0 + l).  Every lane stays active in the row
-        // loops -- lanes past the right edge redo the last pixel (same bytes, same value) instead of leaving
-        const int lorow = tg.row_begin + row0 + lane;
-        int ly = lorow;
-        if (tg.band_world > 1) {
-            const int band = lorow / tg.band_rows;
-            ly = (band * tg.band_world + tg.band_rank) * tg.band_rows + (lorow - band * tg.band_rows);
-        }
-        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < R && row0 + lane < tg.row_count && ly < tg.height);
+    // Sixteen rows at a time (their codes fill a qword), once or -- R == 32 -- twice per wave: what depends on the column
+    // alone (forward + right*sx, the quadratic for |dir|^2) is set up once for all the wave's rows.
+    constexpr int HALVES = R == 32 ? 2 : 1, RH = R / HALVES;
+    const int wrow0 = tile_row0 + wv * R;
+    if (wrow0 < tg.row_count) {
+        typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(4))) const nt_u32x4 *nt_rowtab;
+        uint8_t *const frame_base = tg.dest + (long long)blockIdx.z * tg.frame_stride;
         // What a row loop needs to know about its row -- sy of the ray source and the row's byte offset in a frame -- comes
         // from a table the host wrote (NtTarget::rowtab, 16 bytes per owned row: sy, -, offset), read through the scalar
         // data cache (constant address space: s_load_dwordx4): no vector instruction, nothing per lane
-        typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(4))) const nt_u32x4 *nt_rowtab;
-        const nt_rowtab tab = (nt_rowtab)tg.rowtab + (tg.row_begin + row0);
-        uint8_t *const frame_base = tg.dest + (long long)blockIdx.z * tg.frame_stride;
 #define NT_ROW_LOAD(rr)                     \
         const nt_u32x4 row_e = tab[(rr)];   \
         const float sy = __uint_as_float(row_e.x)
@@ -897,6 +887,45 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
         float base[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) base[j] = fwd[j] + right[j] * sx;
+        // `up` in vector registers: up[j] * sy has the scalar sy as its one scalar operand
+        float upv[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            upv[j] = up[j];
+            asm volatile("" : "+v"(upv[j]));
+        }
+        // packed RGB: the quadratic |dir|^2 = bb - 2 bu sy + uu sy^2 of the guarded rsq quantisation (see box_kernel<N, true>)
+        float bb = 0.0f, bu = 0.0f, uu = 0.0f;
+        bool fastsq = true;
+        if (!F32) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                bb = fmaf(base[j], base[j], bb);
+                bu = fmaf(base[j], up[j], bu);
+                uu = fmaf(up[j], up[j], uu);
+            }
+            fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
+        }
+        const float m2bu = -2.0f * bu;
+        const float maxv = (float)tg.plain_maxval;
+#pragma unroll 1
+        for (int half = 0; half < HALVES; ++half) {
+        const int row0 = wrow0 + 16 * half;
+        if (row0 >= tg.row_count) break;
+        uint32_t redo_bits = 0u;                              // rows (bit rr) left to box_redo_kernel
+        const int cw = (R == 32 ? 4 * wv + 2 * half : 2 * wv);
+        unsigned long long rowcodes = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[cw + 1]) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[cw]);
+        // Which of these rows exist: one row per lane (lane l <-> row row0 + l).  Every lane stays active in the row
+        // loops -- lanes past the right edge redo the last pixel (same bytes, same value) instead of leaving
+        const int lorow = tg.row_begin + row0 + lane;
+        int ly = lorow;
+        if (tg.band_world > 1) {
+            const int band = lorow / tg.band_rows;
+            ly = (band * tg.band_world + tg.band_rank) * tg.band_rows + (lorow - band * tg.band_rows);
+        }
+        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < RH && row0 + lane < tg.row_count && ly < tg.height);
+        const nt_rowtab tab = (nt_rowtab)tg.rowtab + (tg.row_begin + row0);
         const unsigned long long nib = 0x1111111111111111ull;
         unsigned long long validn = valid & 0xffffu;                       // bit rr -> bit 4rr
         validn = (validn | (validn << 24)) & 0x000000ff000000ffull;
@@ -914,25 +943,8 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 skip &= skip - 1ull;
             }
         }
-        // `up` in vector registers: up[j] * sy has the scalar sy as its one scalar operand
-        float upv[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            upv[j] = up[j];
-            asm volatile("" : "+v"(upv[j]));
-        }
         if (!F32) {
             // ---- packed RGB: guarded rsq quantisation (see box_kernel<N, true>)
-            float bb = 0.0f, bu = 0.0f, uu = 0.0f;
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                bb = fmaf(base[j], base[j], bb);
-                bu = fmaf(base[j], up[j], bu);
-                uu = fmaf(up[j], up[j], uu);
-            }
-            const float m2bu = -2.0f * bu;
-            const bool fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
-            const float maxv = (float)tg.plain_maxval;
             if (!fastsq) {
                 todo |= quick | inner;
                 quick = 0ull;
@@ -1081,19 +1093,20 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
             if (!box_pixel<N, !F32, true, false, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit)) redo_bits |= 1u << rr;
         }
+        // mark the rows left over in the redo bitmap (clean on entry: box_redo_kernel zeroes what it has read)
+        if (lane == 0) {
+            while (redo_bits != 0u) {
+                const int rr = __builtin_ctz(redo_bits);
+                redo_bits &= redo_bits - 1u;
+                atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
+            }
+        }
+        }           // (sixteen rows)
     }
 #undef NT_ROW_LOAD
 #undef NT_ROW_OFF
 #undef NT_ROW_PTR
 #undef NT_LANE_OFF
-    // mark the rows left over in the redo bitmap (clean on entry: box_redo_kernel zeroes what it has read)
-    if (lane == 0) {
-        while (redo_bits != 0u) {
-            const int rr = __builtin_ctz(redo_bits);
-            redo_bits &= redo_bits - 1u;
-            atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
-        }
-    }
 }
 
 template <int N>
@@ -1126,7 +1139,10 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
             const int groups = (tg.row_count + 15) / 16;                   // waves with rows, per column
             if ((groups + 2) / 3 * 3 < (groups + 3) / 4 * 4) wpb = 3;
         }
-        const int tile_rows = wpb * (r16 ? 16 : 8);
+        // thirty-two rows a lane, two waves a block (tiles of 64 rows as with 4 x 16: the same codes wave, half the set-up per
+        // row) once the launch is tall enough for the tiles to fit it well
+        const bool r32 = r16 && tg.row_count >= 512;
+        const int tile_rows = r32 ? 64 : wpb * (r16 ? 16 : 8);
         const dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + tile_rows - 1) / tile_rows), (unsigned)li.nframes);
         tg.redo_words = ((tg.width + 63) / 64 + 31) / 32;
         tg.redo = li.cull_buf;                        // [frame][row][redo_words], all zero between launches
@@ -1136,13 +1152,15 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         const int rpb = 4 / split;              // rows per block
         const dim3 rgrid((unsigned)tg.redo_words, (unsigned)((tg.row_count + rpb - 1) / rpb), (unsigned)li.nframes);
         if (fmt_rgb) {
-            if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, false, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
+            if (r32) hipLaunchKernelGGL((box_tile_kernel<N, false, 32, 2>), tgrid, dim3(128), 0, st, cf, tg);
+            else if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, false, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
             else if (r16) hipLaunchKernelGGL((box_tile_kernel<N, false, 16, 4>), tgrid, dim3(256), 0, st, cf, tg);
             else hipLaunchKernelGGL((box_tile_kernel<N, false, 8, 4>), tgrid, dim3(256), 0, st, cf, tg);
             if (split == 2) hipLaunchKernelGGL((box_redo_kernel<N, false, true, 2>), rgrid, dim3(256), 0, st, cf, tg);
             else hipLaunchKernelGGL((box_redo_kernel<N, false, true, 1>), rgrid, dim3(256), 0, st, cf, tg);
         } else {
-            if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
+            if (r32) hipLaunchKernelGGL((box_tile_kernel<N, true, 32, 2>), tgrid, dim3(128), 0, st, cf, tg);
+            else if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
             else if (r16) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 4>), tgrid, dim3(256), 0, st, cf, tg);
             else hipLaunchKernelGGL((box_tile_kernel<N, true, 8, 4>), tgrid, dim3(256), 0, st, cf, tg);
             if (split == 2) hipLaunchKernelGGL((box_redo_kernel<N, true, true, 2>), rgrid, dim3(256), 0, st, cf, tg);
