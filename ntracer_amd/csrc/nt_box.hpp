@@ -811,8 +811,8 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
 // of the launch (a rank's 136 rows of a 1080-row frame: three tiles of 48 rows instead of three of 64).
 template <int N, bool F32, int ROWS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
-    static_assert(ROWS == 8 || ROWS == 16 || ROWS == 32, "sixteen row codes to a qword, one or two qwords a wave");
-    static_assert(WAVES >= 2 && WAVES <= 4, "two to four waves a block");
+    static_assert(ROWS == 8 || ROWS == 16 || ROWS == 32 || ROWS == 64, "sixteen row codes to a qword, one to four qwords a wave");
+    static_assert(WAVES >= 1 && WAVES <= 4 && WAVES * ROWS <= 64, "the codes of a tile are the work of one wave, a row per lane");
     constexpr int R = ROWS;
     __shared__ uint32_t s_code[64];
     const int tid = (int)threadIdx.x;
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
     __syncthreads();
     // Sixteen rows at a time (their codes fill a qword), once or -- R == 32 -- twice per wave: what depends on the column
     // alone (forward + right*sx, the quadratic for |dir|^2) is set up once for all the wave's rows.
-    constexpr int HALVES = R == 32 ? 2 : 1, RH = R / HALVES;
+    constexpr int HALVES = R >= 32 ? R / 16 : 1, RH = R / HALVES;
     const int wrow0 = tile_row0 + wv * R;
     if (wrow0 < tg.row_count) {
         typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
         const int row0 = wrow0 + 16 * half;
         if (row0 >= tg.row_count) break;
         uint32_t redo_bits = 0u;                              // rows (bit rr) left to box_redo_kernel
-        const int cw = (R == 32 ? 4 * wv + 2 * half : 2 * wv);
+        const int cw = (R >= 32 ? (R / 8) * wv + 2 * half : 2 * wv);
         unsigned long long rowcodes = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[cw + 1]) << 32) |
                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[cw]);
         // Which of these rows exist: one row per lane (lane l <-> row row0 + l).  Every lane stays active in the row
@@ -1139,10 +1139,11 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
             const int groups = (tg.row_count + 15) / 16;                   // waves with rows, per column
             if ((groups + 2) / 3 * 3 < (groups + 3) / 4 * 4) wpb = 3;
         }
-        // thirty-two rows a lane, two waves a block (tiles of 64 rows as with 4 x 16: the same codes wave, half the set-up per
-        // row) once the launch is tall enough for the tiles to fit it well
-        const bool r32 = r16 && tg.row_count >= 512;
-        const int tile_rows = r32 ? 64 : wpb * (r16 ? 16 : 8);
+        // sixty-four rows a lane, one wave a block (tiles of 64 rows as with 4 x 16: the wave works out its own codes, and the
+        // set-up per column is shared by four times the rows) once the launch is tall enough for such tiles to fit it well
+        bool r64 = r16 && tg.row_count >= 512;
+        if (const char *e = getenv("NTRACER_BOX_R64")) r64 = r16 && atoi(e) != 0;        // (A/B)
+        const int tile_rows = r64 ? 64 : wpb * (r16 ? 16 : 8);
         const dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + tile_rows - 1) / tile_rows), (unsigned)li.nframes);
         tg.redo_words = ((tg.width + 63) / 64 + 31) / 32;
         tg.redo = li.cull_buf;                        // [frame][row][redo_words], all zero between launches
@@ -1152,14 +1153,14 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         const int rpb = 4 / split;              // rows per block
         const dim3 rgrid((unsigned)tg.redo_words, (unsigned)((tg.row_count + rpb - 1) / rpb), (unsigned)li.nframes);
         if (fmt_rgb) {
-            if (r32) hipLaunchKernelGGL((box_tile_kernel<N, false, 32, 2>), tgrid, dim3(128), 0, st, cf, tg);
+            if (r64) hipLaunchKernelGGL((box_tile_kernel<N, false, 64, 1>), tgrid, dim3(64), 0, st, cf, tg);
             else if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, false, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
             else if (r16) hipLaunchKernelGGL((box_tile_kernel<N, false, 16, 4>), tgrid, dim3(256), 0, st, cf, tg);
             else hipLaunchKernelGGL((box_tile_kernel<N, false, 8, 4>), tgrid, dim3(256), 0, st, cf, tg);
             if (split == 2) hipLaunchKernelGGL((box_redo_kernel<N, false, true, 2>), rgrid, dim3(256), 0, st, cf, tg);
             else hipLaunchKernelGGL((box_redo_kernel<N, false, true, 1>), rgrid, dim3(256), 0, st, cf, tg);
         } else {
-            if (r32) hipLaunchKernelGGL((box_tile_kernel<N, true, 32, 2>), tgrid, dim3(128), 0, st, cf, tg);
+            if (r64) hipLaunchKernelGGL((box_tile_kernel<N, true, 64, 1>), tgrid, dim3(64), 0, st, cf, tg);
             else if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
             else if (r16) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 4>), tgrid, dim3(256), 0, st, cf, tg);
             else hipLaunchKernelGGL((box_tile_kernel<N, true, 8, 4>), tgrid, dim3(256), 0, st, cf, tg);
