@@ -365,31 +365,35 @@ def test_lit_reflective_scene_in_ten_dimensions_vs_oracle(monkeypatch, force_var
     assert img.view(">f4").max() > 0.3
 
 
-def test_twelve_dimensional_lit_scene_vs_reference_and_oracle():
+def test_twelve_dimensional_lit_scene_vs_reference_and_oracle(monkeypatch):
     """lit12_n12, captured from the reference's generic module: simplices (batched and loose), a Solid cube and sphere,
-    point + global light, shadows, reflection depth 2 -- n = 12 is beyond the compile-time-N kernels, so this is
-    composite_kernel_var with everything on.  (For n > 10 a hit keeps its own normal; the reference's o_hit.normal
-    scribbling moves 4 of these 10 600 samples.)"""
+    point + global light, shadows, reflection depth 2 -- n = 12 is beyond the compile-time-N kernels.  Solids are there,
+    so the default is composite_kernel_var_t<true> (the reference's o_hit.normal handling): the default-mode oracle to 1e-5;
+    NTRACER_CLEAN_NORMALS=1 is composite_kernel_var and the clean-mode oracle.  Against the reference's own colours a
+    handful of the 10 600 samples differ in either mode, as the oracle's do (test_oracle_golden.py: 5 and 9)."""
     g = fx.load("lit12_n12")
     flat = fx.flat_of(g)
     p = fx.params_of(g)
     sc = tracern.CompositeScene.from_flat(12, flat)
     sc.set_params_flat(p)
-    bad = total = 0
-    for k, f in enumerate(g["frames"]):
-        sc._set_camera_arrays(g["origins"][f], g["axes"][f])
-        c = sc.colors_at(g["xs"], g["ys"], 160, 100)
-        o = ob.OracleScene(12, g["origins"][f], g["axes"][f], flat=flat, params=p, clean_normals=True).colors_at(g["xs"], g["ys"], 160, 100)
-        assert np.abs(c - o).max() < TOL_ORACLE, int(f)
-        d = np.abs(c - g["colors"][k]).max(axis=1)
-        bad += int((d > TOL_REF).sum())
-        total += len(d)
-    assert bad <= 0.005 * total, bad
-    # image path
-    sc._set_camera_arrays(g["origins"][7], g["axes"][7])
-    img = render_host(sc, fmt_of(160, 100, fx.RGBF32))
-    ref = ob.OracleScene(12, g["origins"][7], g["axes"][7], flat=flat, params=p, clean_normals=True).render(160, 100, fx.RGBF32, threads=7)
-    assert np.abs(img.view(">f4") - ref.view(">f4")).max() < TOL_ORACLE
+    for clean in (False, True):
+        if clean:
+            monkeypatch.setenv("NTRACER_CLEAN_NORMALS", "1")
+        bad = total = 0
+        for k, f in enumerate(g["frames"]):
+            sc._set_camera_arrays(g["origins"][f], g["axes"][f])
+            c = sc.colors_at(g["xs"], g["ys"], 160, 100)
+            o = ob.OracleScene(12, g["origins"][f], g["axes"][f], flat=flat, params=p, clean_normals=clean).colors_at(g["xs"], g["ys"], 160, 100)
+            assert np.abs(c - o).max() < TOL_ORACLE, (int(f), clean)
+            d = np.abs(c - g["colors"][k]).max(axis=1)
+            bad += int((d > TOL_REF).sum())
+            total += len(d)
+        assert bad <= 0.002 * total, (bad, clean)
+        # image path
+        sc._set_camera_arrays(g["origins"][7], g["axes"][7])
+        img = render_host(sc, fmt_of(160, 100, fx.RGBF32))
+        ref = ob.OracleScene(12, g["origins"][7], g["axes"][7], flat=flat, params=p, clean_normals=clean).render(160, 100, fx.RGBF32, threads=7)
+        assert np.abs(img.view(">f4") - ref.view(">f4")).max() < TOL_ORACLE, clean
 
 
 @pytest.mark.parametrize("clean", [False, True])
