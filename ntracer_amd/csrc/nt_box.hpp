@@ -130,15 +130,18 @@ __device__ __forceinline__ void box_classify(const float (&o)[N], const float (&
     tn = -INFINITY;
     vK = 0.0f;
     float tnp = -INFINITY, tfp = INFINITY;                 // last entry / first exit, cube grown by m
+    const float m1p = 1.0f + m;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
+        // slab j: (+-1 - o_j)/v_j = c -+ |1/v_j| with c = -o_j/v_j; grown by m: c -+ (1 + m)|1/v_j|.  (v_j = 0: inf - inf
+        // is a NaN, which drops out of fmaxf / fminf -- right for an origin inside the slab; one outside it goes
+        // undetected here and ends up unclear, but box_stretch_code culls such stretches before anyone looks at a ray)
         const float inv = __builtin_amdgcn_rcpf(v[j]);
-        const float a = (-1.0f - o[j]) * inv, b = (1.0f - o[j]) * inv;
-        const float nr = fminf(a, b), fr = fmaxf(a, b);     // a NaN (v_j = 0 and o_j = -+1, or 0*inf) drops out
+        const float c0 = -o[j] * inv;
+        const float nr = c0 - fabsf(inv);
         near[j] = nr;
-        const float w = m * fabsf(inv);
-        tnp = fmaxf(tnp, nr - w);
-        tfp = fminf(tfp, fr + w);
+        tnp = fmaxf(tnp, fmaf(-fabsf(inv), m1p, c0));
+        tfp = fminf(tfp, fmaf(fabsf(inv), m1p, c0));
         const bool later = nr > tn;
         tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);
         vK = later ? v[j] : vK;
@@ -169,7 +172,7 @@ __device__ __forceinline__ void box_entries(const float (&o)[N], const float (&v
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const float inv = __builtin_amdgcn_rcpf(v[j]);
-        const float nr = fminf((-1.0f - o[j]) * inv, (1.0f - o[j]) * inv);
+        const float nr = fmaf(-o[j], inv, -fabsf(inv));          // (+-1 - o_j)/v_j, the earlier of the two
         near[j] = nr;
         vK = nr > tn ? v[j] : vK;
         tn = fmaxf(tn, nr);
