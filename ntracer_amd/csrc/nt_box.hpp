@@ -196,6 +196,7 @@ __device__ __forceinline__ void box_resolve(const float (&o)[N], const float (&v
     const float slack = m * __builtin_amdgcn_rcpf(aK), lim = 1.0f - 0.5f * m;
     bool inT[N], inC[N];
     float d[N];
+    uint32_t anyC = 0u;                       // coordinates in some lane's C (uniform): the others are not looked at below
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const bool early = (tn - near[j]) * aK > m;                                     // false for a NaN
@@ -203,7 +204,10 @@ __device__ __forceinline__ void box_resolve(const float (&o)[N], const float (&v
         inT[j] = unclear && !early;
         inC[j] = unclear && !(robust && early);
         d[j] = 0.0f;
-        if (__builtin_amdgcn_ballot_w64(inC[j]) != 0ull) d[j] = v[j] / len;
+        if (__builtin_amdgcn_ballot_w64(inC[j]) != 0ull) {
+            d[j] = v[j] / len;
+            anyC |= 1u << j;
+        }
     }
     bool done = false, found = false;
     float xs = v[0];
@@ -216,7 +220,7 @@ __device__ __forceinline__ void box_resolve(const float (&o)[N], const float (&v
             bool ok = cand && di != 0.0f && dist > 0.0f;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                if (j != i) {
+                if (j != i && ((anyC >> j) & 1u) != 0u) {
                     const float p = d[j] * dist + o[j];
                     ok = ok && !(inC[j] && fabsf(p) > (1.0f + NT_FUZZ));
                 }
