@@ -308,7 +308,9 @@ template <int N, bool PLAIN, bool DEFER = false, bool REDO = false, bool F32 = f
 __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
                                           const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true) {
     // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
-    const bool maybe = REDO || (rowhit && box_may_hit(N, dots, sx, sy, sq));
+    // (DEFER: the callers pass the code of the stretch as rowhit -- a stretch that survived the codes wave is next to the
+    // cube, where the circumsphere test rarely spares a wave the classification and costs eight instructions every time)
+    const bool maybe = REDO || (rowhit && (DEFER || box_may_hit(N, dots, sx, sy, sq)));
     float r, g, b;
     bool hit = false, unclear = false;
     float x = dir[0];
