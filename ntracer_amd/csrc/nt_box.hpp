@@ -350,6 +350,12 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
             const bool clear_gb = fabsf(__builtin_amdgcn_fractf(tgb) - 0.5f) > fmaf(tgb, 0x1p-20f, 0x1p-20f);
             const bool clear_r = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-20f, 0x1p-20f);
             if (__builtin_amdgcn_ballot_w64(!(clear_gb && (clear_r || !hit))) == 0ull) {
+                if (tg.plain_sel != 0u) {
+                    // 8-bit fields: t + 2^23 holds round(t) in its low mantissa byte (see box_tile_kernel), the byte v_perm_b32 picks
+                    const uint32_t q8gb = __float_as_uint(tgb + 8388608.0f), q8r = __float_as_uint(t + 8388608.0f);
+                    *reinterpret_cast<uint32_t *>(tg.dest + pr.offset) = __builtin_amdgcn_perm((hit || x > 0.0f) ? q8r : 0u, q8gb, tg.plain_sel);
+                    return true;
+                }
                 uint32_t qgb = (uint32_t)(tgb + 0.5f), qr = (uint32_t)(t + 0.5f);
                 qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;    // the value may round to just above 1: clamped
                 qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
