@@ -246,7 +246,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "valu": valu,
                      "algorithmic_bytes_per_launch": float(own_rows) * W * fmt.bytes_per_pixel * F,
-                     "kernel": "box_tile_kernel<6, false, 64, 1> (with box_redo_kernel<6, false, true, 1> after it: one "
+                     "kernel": "box_tile_kernel<6, false, ROWS, WAVES> (64, 1 for the full frame) with box_redo_kernel<6, false, true, SPLIT> after it (one "
                                "nt_render_frames_device call = these two + the camera upload kernel)",
                      "avg_launch_us": round(kernel_us, 2),
                      "algorithmic_bytes_per_ray": fmt.bytes_per_pixel,

@@ -320,6 +320,52 @@ def test_ragged_and_tiny_images():
             assert np.array_equal(img, osc.render(w, h, chans)), (w, h)
 
 
+def test_row_tables_of_many_launch_geometries():
+    """The tile kernel reads sy and the row offsets from a table the host keeps per launch geometry (view, fov, pitch, band
+    split; a handful cached, the oldest dropped): a dozen geometries on one scene, the first ones again afterwards, a
+    changed fov, padded pitches and band splits -- every image equals the oracle's."""
+    g = fx.load("box_n6_1920x1080")
+    sc = tracern.BoxScene(6)
+    sc._set_camera_arrays(g["origins"][23], g["axes"][23])
+    osc = ob.OracleScene(6, g["origins"][23], g["axes"][23])
+    sizes = [(200, 40 + 3 * k) for k in range(12)] + [(200, 40), (200, 43)]
+    for (w, h) in sizes:
+        for pitch in (0, 4 * w + 64):
+            img = render_host(sc, fmt_of(w, h, fx.RGBX8, pitch))
+            ref = osc.render(w, h, fx.RGBX8)
+            assert np.array_equal(img[:, :4 * w], ref), (w, h, pitch)
+    sc.set_fov(1.1)
+    osc2 = ob.OracleScene(6, g["origins"][23], g["axes"][23], 1.1)
+    assert np.array_equal(render_host(sc, fmt_of(200, 40, fx.RGBX8)), osc2.render(200, 40, fx.RGBX8))
+    # rows dealt in bands, into a full-size frame (rows of a wave are not `pitch` apart) and into a compact one
+    import torch
+    w, h = 320, 200
+    fmt = fmt_of(w, h, fx.RGBX8)
+    full = osc2.render(w, h, fx.RGBX8)
+    fst = fmt._as_struct()
+    o1 = np.ascontiguousarray(g["origins"][23:24], np.float32)
+    a1 = np.ascontiguousarray(g["axes"][23:24], np.float32)
+    from ntracer_amd import distributed as ntd
+    for world, rows in ((3, 8), (4, 16)):
+        for compact in (0, 1):
+            for rank in range(world):
+                own = ntd.owned_rows(h, rank, world, rows)
+                opts = _lib.NtRenderOpts()
+                opts.device = 0
+                opts.band_rank, opts.band_world, opts.band_rows, opts.compact = rank, world, rows, compact
+                nrows = len(own) if compact else h
+                fb = torch.zeros((nrows * fmt.pitch,), dtype=torch.uint8, device="cuda")
+                _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), nrows * fmt.pitch, 1, o1.ctypes.data_as(_lib.f32p),
+                                                              a1.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts),
+                                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                torch.cuda.synchronize()
+                got = fb.cpu().numpy().reshape(nrows, fmt.pitch)
+                if compact:
+                    assert np.array_equal(got, full[own]), (world, rows, rank)
+                else:
+                    assert np.array_equal(got[own], full[own]), (world, rows, rank)
+
+
 # ------------------------------------------------------------------ CompositeScene (config 4)
 def test_simplex10_fixed_and_run_time_n_kernels_agree(monkeypatch):
     """A 10-D composite scene renders through launch_composite_fixed<10> by default and through
