@@ -306,8 +306,10 @@ __device__ __forceinline__ float sqrt_wave(float x) {
 // sorting of the others saves nothing.
 template <int N, bool PLAIN, bool DEFER = false, bool REDO = false, bool F32 = false>
 __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
-                                          const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true) {
+                                          const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true, int face = -1) {
     // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
+    // face (wave-uniform) >= 0: every ray of the stretch is known to hit that face (a one-face row of box_tile_kernel whose
+    // cheap quantisation came too close to a rounding boundary): nothing to sort, only the exact colour is wanted
     // (DEFER: the callers pass the code of the stretch as rowhit -- a stretch that survived the codes wave is next to the
     // cube, where the circumsphere test rarely spares a wave the classification and costs eight instructions every time)
     const bool maybe = REDO || (rowhit && (DEFER || box_may_hit(N, dots, sx, sy, sq)));
@@ -316,7 +318,11 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
     float x = dir[0];
 #ifndef NT_EXP_NOCLASSIFY
     float near[N], tn = 0.0f, vK = 0.0f;
-    if (REDO) {
+    if (face >= 0) {
+        hit = true;
+#pragma unroll
+        for (int j = 1; j < N; ++j) x = face == j ? dir[j] : x;
+    } else if (REDO) {
         box_entries<N>(org, dir, near, tn, vK);
         unclear = true;
     } else if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
@@ -1106,7 +1112,10 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             float sq = dir[0] * dir[0];
 #pragma unroll
             for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-            if (!box_pixel<N, !F32, true, false, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit)) redo_bits |= 1u << rr;
+            // (a row with a face code is here because its cheap quantisation failed: the face is known)
+            const int rcode = (int)((uint32_t)(rowcodes >> (4 * rr)) & 15u);
+            if (!box_pixel<N, !F32, true, false, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit, rcode >= 1 && rcode <= 13 ? rcode - 1 : -1))
+                redo_bits |= 1u << rr;
         }
         // mark the rows left over in the redo bitmap (clean on entry: box_redo_kernel zeroes what it has read)
         if (lane == 0) {
