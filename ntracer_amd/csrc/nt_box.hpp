@@ -819,17 +819,20 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
 // The fused path for the two formats the reference's scripts render into (packed plain RGB of <= 10 bits a channel in
 // one aligned dword -- RGBX8 & co.: F32 = false; three plain fp32 channels, 12-byte pixels: F32 = true):
 //
-//   box_tile_kernel<N, F32, ROWS>   a block = 64 columns x 4*ROWS rows.  One wave first works out the stretch codes of the
-//                                   tile (box_stretch_code, one row per lane) and leaves them in LDS; after the barrier
-//                                   every wave renders its ROWS rows from them with the lean loops.  A row it cannot settle
-//                                   (code 14, or a lane that needs the reference's face-by-face arithmetic) gets its bit
-//                                   set in the redo bitmap, [frame][row][word of 32 stretches], with an atomic OR.
+//   box_tile_kernel<N, F32, ROWS, WAVES>   a block = 64 columns x WAVES*ROWS rows (at most 64: one row per lane of the wave
+//                                   that works out the stretch codes, box_stretch_code, and leaves them in LDS); after the
+//                                   barrier every wave renders its ROWS rows from them with the lean loops, sixteen rows (a
+//                                   qword of codes) at a time.  Per-row parameters come from the host's row table through
+//                                   scalar loads (NtTarget::rowtab).  A row it cannot settle (code 14, or a lane that needs
+//                                   the reference's face-by-face arithmetic) gets its bit set in the redo bitmap,
+//                                   [frame][row][word of 32 stretches], with an atomic OR.
 //   box_redo_kernel<N, F32>         one wave per (frame, row, word): the marked stretches with box_pixel<REDO>; it hands the
 //                                   word back zeroed, so the bitmap is clean for the next launch (the host zeroes it once).
 // No pre-kernel; the only scratch is the bitmap (one bit per 64 pixels).
 // --------------------------------------------------------------------------------------
-// WAVES: waves per block, i.e. the tile is 64 x WAVES*ROWS pixels -- 4 unless fewer leave fewer idle waves below the last row
-// of the launch (a rank's 136 rows of a 1080-row frame: three tiles of 48 rows instead of three of 64).
+// ROWS x WAVES: 64 x 1 for launches of 512 rows or more with waves to spare (what depends on the column alone is set up once
+// for 64 rows); otherwise 16 (8 in small launches) x 4, or x 3 when that leaves fewer idle waves below the last row of the
+// launch (a rank's 136 rows of a 1080-row frame: three tiles of 48 rows instead of three of 64).
 template <int N, bool F32, int ROWS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
     static_assert(ROWS == 8 || ROWS == 16 || ROWS == 32 || ROWS == 64, "sixteen row codes to a qword, one to four qwords a wave");
