@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+STORE_ONLY_GBS = 5650.0       # 64 x 64-pixel tiles, 256 bytes per store instruction: tools/micro/store_rate.hip on MI355X
 SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4                # max clock (MI355X_MICROARCH.md)
 PROFILE = "r02_pmc_summary.json"       # profiles/: rocprofv3 --pmc passes of THIS build (tools/profile_round.sh)
@@ -245,6 +246,9 @@ def main():
                    "framebuffer": "resident in HBM (one buffer per frame)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "valu": valu,
+                     # what kernels that only store reach on this part in the tile kernel's pattern (measured once with
+                     # tools/micro/store_rate.hip, recorded in profiles/README.md): the practical ceiling of this workload
+                     "store_only": {"GBs": STORE_ONLY_GBS, "frac": round(achieved / STORE_ONLY_GBS, 4), "source": "tools/micro/store_rate.hip"},
                      "algorithmic_bytes_per_launch": float(own_rows) * W * fmt.bytes_per_pixel * F,
                      "kernel": "box_tile_kernel<6, false, ROWS, WAVES> (64, 1 for the full frame) with box_redo_kernel<6, false, true, SPLIT> after it (one "
                                "nt_render_frames_device call = these two + the camera upload kernel)",
