@@ -106,9 +106,11 @@ __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir
 
 // m of box_classify / box_resolve / box_cull_kernel, per unit of 1 + max|o_j|.  What it has to dominate:
 // ROUNDING_FUZZ (1.2e-6), the reference's own rounding in p_j (<= (5|o_j| + 6)*2^-24) and the v_rcp_f32 arithmetic
-// here (~2^-22*(1 + |o_j|)): under 2e-6*(1 + max|o_j|) together, 15x below this.
+// here (~2^-22*(1 + |o_j|)): under 2e-6*(1 + max|o_j|) together, 5x below this.  (Rounds 1 and most of 2 ran with 3e-5; the
+// narrower band sends a third fewer stretches to box_redo_kernel.  Builds with -DNT_BOX_MARGIN=2e-6f, the bound itself, and
+// 5e-6f render the 440 full frames of tools/box_soak.py byte for byte like the oracle; at 5e-7f frames start to differ.)
 #ifndef NT_BOX_MARGIN
-#define NT_BOX_MARGIN 3e-5f
+#define NT_BOX_MARGIN 1e-5f
 #endif
 // Which rays need the exact evaluation at all?  Everything below works on the UNNORMALISED direction v
 // (p_j(tau) = o_j + v_j*tau; the reference's dist is tau*|v|), with reciprocals from v_rcp_f32, and sorts a lane
