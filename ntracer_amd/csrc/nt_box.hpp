@@ -337,7 +337,7 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
     } else {
         const bool hard = unclear && !(tn > 1e-3f && tn < 1e30f);
         if (__builtin_amdgcn_ballot_w64(unclear) != 0ull && __builtin_amdgcn_ballot_w64(hard) == 0ull) {
-            box_resolve<N>(org, dir, sqrtf(sq), margin, near, tn, vK, unclear, hit, x);
+            box_resolve<N>(org, dir, sqrt_wave(sq), margin, near, tn, vK, unclear, hit, x);
             unclear = false;
         }
     }
