@@ -972,6 +972,38 @@ def test_bench_workload_every_frame_equals_the_oracle():
         assert np.array_equal(got[f], ref), f
 
 
+@pytest.mark.parametrize("n,chans", [(4, "rgbx8"), (8, "rgbx8"), (10, "rgbf32")])
+def test_tall_launches_take_sixty_four_rows_a_wave(n, chans):
+    """Launches of 512 rows or more with 32k tiles to go round run box_tile_kernel<N, F32, 64, 1> (one wave per 64 x 64
+    tile); the bench frames cover that for n = 3 and 6 -- here 72 random cameras at 1080p for other dimensions and the fp32
+    format, every sixth frame against the oracle byte for byte."""
+    import torch
+    rng = np.random.default_rng(700 + n)
+    w, h, nf = 1920, 1080, 72
+    fmt = fmt_of(w, h, fx.RGBX8 if chans == "rgbx8" else fx.RGBF32)
+    origins, axes = [], []
+    for k in range(nf):
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        q = np.ascontiguousarray(q, np.float32)
+        dist = float(rng.choice([1.6, 2.5, 4.0, 7.0]))
+        origins.append((-q[2] * np.float32(dist) + np.float32(rng.uniform(-0.5, 0.5)) * q[0]).astype(np.float32))
+        axes.append(q)
+    o = np.ascontiguousarray(np.stack(origins), np.float32)
+    a = np.ascontiguousarray(np.stack(axes), np.float32)
+    sc = tracern.BoxScene(n)
+    fb = torch.zeros((nf, h * fmt.pitch), dtype=torch.uint8, device="cuda")
+    st_ = fmt._as_struct()
+    _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), h * fmt.pitch, nf, o.ctypes.data_as(_lib.f32p),
+                                                  a.ctypes.data_as(_lib.f32p), C.byref(st_), None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = fb.cpu().numpy().reshape(nf, h, fmt.pitch)
+    osc = ob.OracleScene(n, o[0], a[0])
+    for f in range(0, nf, 6):
+        osc.set_camera(o[f], a[f])
+        ref = osc.render(w, h, fx.RGBX8 if chans == "rgbx8" else fx.RGBF32, threads=7)
+        assert np.array_equal(got[f], ref), (n, f)
+
+
 def test_bench_workload_in_bands_and_in_float_channels():
     """The large-launch tile shape (sixteen rows a lane) in the two other guises the bench uses: (1) one rank's bands of an
     8-GPU run -- rows dealt in bands of 8, compact buffer -- must be the corresponding rows of the whole frames (which
