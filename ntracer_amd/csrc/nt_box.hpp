@@ -1180,7 +1180,9 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         tg.redo = li.cull_buf;                        // [frame][row][redo_words], all zero between launches
         // few rows in flight: two waves per redo word
         const long long rwords = (long long)tg.row_count * li.nframes * tg.redo_words;
-        const int split = rwords < 96 * 1024 ? 2 : 1;           // (four waves a word measured slower than two)
+        int split = rwords < 48 * 1024 ? 2 : 1;                 // (87k words: one wave 3 % faster; 44k: even; 22k: two waves 2 % faster;
+                                                                //  four waves a word measured slower than two)
+        if (const char *e = getenv("NTRACER_BOX_SPLIT")) split = atoi(e) == 2 ? 2 : 1;        // (A/B)
         const int rpb = 4 / split;              // rows per block
         const dim3 rgrid((unsigned)tg.redo_words, (unsigned)((tg.row_count + rpb - 1) / rpb), (unsigned)li.nframes);
         if (fmt_rgb) {
