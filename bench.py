@@ -72,6 +72,10 @@ def valu_bound(call, measured_us):
            "peak": "1 VALU wave-instruction / SIMD / 2 cycles @ 2.4 GHz (= 157 TFLOP/s fp32)", "issue_limited_us": round(limited_us, 2),
            "measured_us": round(measured_us, 2), "frac": round(limited_us / measured_us, 4),
            "source": "profiles/" + PROFILE}
+    # ... and at the rate non-packed wave64 instructions can actually issue on a 16-lane SIMD, one per 4 cycles
+    # (v_pk_fma_f32 is the only way to the spec rate; the kernels' average is 4.2 cycles per instruction)
+    out["issue_limited_us_wave64"] = round(2.0 * limited_us, 2)
+    out["frac_wave64"] = round(2.0 * limited_us / measured_us, 4)
     if active and cycles:
         # SQ_ACTIVE_INST_VALU: quad-cycles in which a SIMD's VALU was executing (MI355X_MICROARCH.md); half-rate and
         # transcendental instructions (v_cndmask, v_perm, v_cvt, v_rsq ...) hold it 4 - 8 cycles, cf. tools/micro/valu_rate.hip
