@@ -552,6 +552,26 @@ def test_eleven_dimensional_feature_scene_vs_reference(monkeypatch):
     assert np.abs(img.view(">f4") - ref.view(">f4")).max() < TOL_ORACLE
 
 
+def test_sixteen_dimensional_feature_scene_vs_reference():
+    """feature16_n16 (the reference's generic module in sixteen dimensions: transparent and reflective simplices, Solids,
+    lights, shadows) through composite_kernel_var_t: the oracle's colours to 1e-5, the reference's to 1e-4."""
+    g = fx.load("feature16_n16")
+    flat = fx.flat_of(g)
+    p = fx.params_of(g)
+    sc = tracern.CompositeScene.from_flat(16, flat)
+    sc.set_params_flat(p)
+    for k, f in enumerate(g["frames"]):
+        sc._set_camera_arrays(g["origins"][f], g["axes"][f])
+        c = sc.colors_at(g["xs"], g["ys"], 160, 100)
+        o = ob.OracleScene(16, g["origins"][f], g["axes"][f], flat=flat, params=p).colors_at(g["xs"], g["ys"], 160, 100)
+        assert np.abs(c - o).max() < TOL_ORACLE, int(f)
+        assert np.abs(c - g["colors"][k]).max() < TOL_REF, int(f)
+    f = int(g["frames"][1])
+    img = render_host(sc, fmt_of(160, 100, fx.RGBF32))
+    ref = ob.OracleScene(16, g["origins"][f], g["axes"][f], flat=flat, params=p).render(160, 100, fx.RGBF32, threads=7)
+    assert np.abs(img.view(">f4") - ref.view(">f4")).max() < TOL_ORACLE
+
+
 def test_reflection_among_transparent_things_to_any_depth():
     """Two mirrors facing each other with a half-transparent, slightly reflective pane and an opaque triangle between them,
     max_reflect_depth = 12: beyond the six ray_color frames the compile-time-N transparency kernel keeps, so the launch

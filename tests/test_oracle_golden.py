@@ -162,6 +162,16 @@ def test_eleven_dimensional_feature_scene_matches_the_reference():
     assert differ_clean > 0
 
 
+def test_sixteen_dimensional_feature_scene_matches_the_reference():
+    """feature16_n16: the same kind of scene in sixteen dimensions (the reference's generic module again)."""
+    g = fx.load("feature16_n16")
+    flat = fx.flat_of(g)
+    p = fx.params_of(g)
+    for k, f in enumerate(g["frames"]):
+        c = ob.OracleScene(16, g["origins"][f], g["axes"][f], flat=flat, params=p).colors_at(g["xs"], g["ys"], 160, 100)
+        assert np.abs(c - g["colors"][k]).max() < TOL, int(f)
+
+
 def test_clean_mode_only_differs_where_the_alias_bites():
     g = fx.load("cell600_n4")
     f = g["frames"][1]

@@ -650,6 +650,7 @@ if __name__ == "__main__":
         # (feature5_n5 was captured with the point light (3e4, 2.8e4, 2.5e4); regenerating it changes that light a little)
         "feature5": lambda: gen_feature_n(5, "feature5_n5"),
         "feature11": lambda: gen_feature_n(11, "feature11_n11", frames=(0, 9, 21)),
+        "feature16": lambda: gen_feature_n(16, "feature16_n16", frames=(3, 17)),
     }
     for k, f in jobs.items():
         if a.only is None or k in a.only:
