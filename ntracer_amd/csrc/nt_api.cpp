@@ -728,7 +728,9 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             const size_t words = (size_t)(((tg.width + 63) / 64 + 31) / 32);
             // stretch codes (4 words per redo word), 16 rows of padding (box_kernel reads a wave's rows without
             // clamping), redo bits
-            const size_t need = ((size_t)5 * job.nframes * tg.row_count + 64) * words * sizeof(uint32_t);
+            // (the fused kernels: redo bits, then one dword per stretch for the tie sets)
+            const size_t need = std::max(((size_t)5 * job.nframes * tg.row_count + 64) * words * sizeof(uint32_t),
+                                         (size_t)job.nframes * tg.row_count * (words + (size_t)((tg.width + 63) / 64)) * sizeof(uint32_t));
             if (need > ds->cull.cap || !ds->cull.p) ds->cull_clean = false;
             if (int e = ds->cull.ensure(need)) return e;
             // The fused kernels keep their redo bitmap at the start of this buffer and leave it zeroed; after anything else

@@ -308,7 +308,8 @@ __device__ __forceinline__ float sqrt_wave(float x) {
 // sorting of the others saves nothing.
 template <int N, bool PLAIN, bool DEFER = false, bool REDO = false, bool F32 = false>
 __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
-                                          const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true, int face = -1) {
+                                          const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true, int face = -1,
+                                          uint32_t sets = 0u) {
     // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
     // face (wave-uniform) >= 0: every ray of the stretch is known to hit that face (a one-face row of box_tile_kernel whose
     // cheap quantisation came too close to a rounding boundary): nothing to sort, only the exact colour is wanted
@@ -324,6 +325,38 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
         hit = true;
 #pragma unroll
         for (int j = 1; j < N; ++j) x = face == j ? dir[j] : x;
+    } else if (REDO && (sets & 0x80000000u) != 0u) {
+        // sets (wave-uniform, box_redo_kernel): T and C of the whole stretch from the codes wave (box_stretch_code) -- the
+        // reference's arithmetic on them, as in box_resolve, without the entry times
+        const float len = sqrt_wave(sq);
+        float d[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            d[j] = 0.0f;
+            if ((sets >> (10 + j)) & 1u) d[j] = dir[j] / len;
+        }
+        bool done = false;
+        x = dir[0];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (((sets >> i) & 1u) != 0u && __builtin_amdgcn_ballot_w64(!done) != 0ull) {
+                const float di = d[i];
+                const float dist = ((di < 0.0f ? 1.0f : -1.0f) - org[i]) / di;
+                bool ok = !done && di != 0.0f && dist > 0.0f;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    if (j != i && ((sets >> (10 + j)) & 1u) != 0u) {
+                        const float p = d[j] * dist + org[j];
+                        ok = ok && !(fabsf(p) > (1.0f + NT_FUZZ));
+                    }
+                }
+                if (ok) {
+                    done = true;
+                    // `if(dist >= cutoff) return 0` with cutoff = FLT_MAX (tracer.hpp:142): a miss
+                    if (!(dist >= FLT_MAX)) { hit = true; x = dir[i]; }
+                }
+            }
+        }
     } else if (REDO) {
         box_entries<N>(org, dir, near, tn, vK);
         unclear = true;
@@ -693,7 +726,12 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
         float sq = dir[0] * dir[0];
 #pragma unroll
         for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
-        box_pixel<N, !F32, false, true, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin);
+        uint32_t sets = 0u;
+        if (tg.tie_sets) {
+            const int stretch = (int)blockIdx.x * 32 + bit;
+            sets = (uint32_t)__builtin_amdgcn_readfirstlane((int)tg.tie_sets[((size_t)blockIdx.z * tg.row_count + row) * ((tg.width + 63) / 64) + stretch]);
+        }
+        box_pixel<N, !F32, false, true, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, true, -1, sets);
     }
 }
 
@@ -715,9 +753,18 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
 //    box_redo_kernel renders it (its redo bit is set here).
 // Reciprocals are approximate (v_rcp_f32); the slacks above are ~1000x their error.
 // The code of one 64-pixel stretch (see the comment above): row y of the image, stretch `col` of the row.
+// `sets` (box_tile_kernel): for a code-14 stretch, what box_resolve works out ray by ray from entry times -- the faces T that
+// can still be the reference's answer and the coordinates C one of them could fail at -- as supersets valid for EVERY ray
+// of the stretch (bits 0..9: T, bits 10..19: C, bit 31: valid), so that box_redo_kernel goes straight to the reference's
+// arithmetic on them.  With [A_j, B_j] the range of slab j's entry time over the stretch's directions: every ray's last
+// entry is at or after TN = max_j A_j; M = m / (the smallest |v_j| of an axis that can be last, B_j >= TN) is at least the
+// ray's m/|v_K|; so a face within m/|v_K| of a ray's last entry has B_j >= TN - M: that is T.  The entries of T's faces
+// lie in [TN - M, max_j B_j]; a coordinate that stays inside 1 - m over that span of tau, for all the stretch's
+// directions, passes every test made there: the others, and T itself, are C.  No valid sets when a candidate's v_j
+// changes sign in the stretch or TN - M is not clearly positive (rays starting on or in the cube: box_color's business).
 template <int N>
 __device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], const float (&right)[N], const float (&up)[N], const float (&fwd)[N],
-                                                     const NtTarget &tg, int y, int col) {
+                                                     const NtTarget &tg, int y, int col, uint32_t *sets = nullptr) {
     uint32_t code = 0u;
     float omax = fabsf(org[0]);
 #pragma unroll
@@ -782,7 +829,47 @@ __device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], cons
         // The middle ray enters two slabs within m/|v_K| of each other: box_classify would call the rays around it
         // unclear and box_kernel would hand the stretch to box_redo_kernel after classifying all of it -- send it
         // there directly (code 14; only a prediction: box_redo_kernel is right for any stretch).
-        if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) code = 14u;
+        if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) {
+            code = 14u;
+            if (sets != nullptr && N <= 10) {
+                float A[N], B[N];
+                float TN = -INFINITY, TH = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float va = vc[j] - g[j], vb = vc[j] + g[j];
+                    const float num = (vc[j] < 0.0f ? 1.0f : -1.0f) - org[j];
+                    const float e1 = num * __builtin_amdgcn_rcpf(va), e2 = num * __builtin_amdgcn_rcpf(vb);
+                    const float lo = fminf(e1, e2), hi = fmaxf(e1, e2);
+                    const bool same = va * vb > 0.0f;
+                    A[j] = same ? lo - fabsf(lo) * 1e-6f : -INFINITY;          // (v_rcp_f32: 1 ulp)
+                    B[j] = same ? hi + fabsf(hi) * 1e-6f : INFINITY;
+                    TN = fmaxf(TN, A[j]);
+                    TH = fmaxf(TH, B[j]);
+                }
+                float vmin = INFINITY;                  // the smallest |v_j| an axis that can be last has anywhere in the stretch
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float va = vc[j] - g[j], vb = vc[j] + g[j];
+                    if (B[j] >= TN) vmin = fminf(vmin, va * vb > 0.0f ? fminf(fabsf(va), fabsf(vb)) : 0.0f);
+                }
+                const float M = m * __builtin_amdgcn_rcpf(vmin) * (1.0f + 1e-5f);
+                const float t_lo = TN - M, t_hi = TH;
+                uint32_t T = 0u, C = 0u;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float va = vc[j] - g[j], vb = vc[j] + g[j];
+                    const bool inT = B[j] >= t_lo;
+                    const float pmax = org[j] + fmaxf(vb * t_lo, vb * t_hi);
+                    const float pmin = org[j] + fminf(va * t_lo, va * t_hi);
+                    const float lim = 1.0f - m - 1e-4f;
+                    const bool inC = inT || !(pmax <= lim && pmin >= -lim);
+                    T |= inT ? 1u << j : 0u;
+                    C |= inC ? 1u << j : 0u;
+                }
+                const bool valid = vmin > 0.0f && t_lo > 1e-3f && t_hi < 1e30f;         // (a NaN fails)
+                *sets = valid ? (0x80000000u | (C << 10) | T) : 0u;
+            }
+        }
     }
     return code;
 }
@@ -870,7 +957,12 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 const int band = orow / tg.band_rows;
                 y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
             }
-            if (y < tg.height) code = box_stretch_code<N>(org, right, up, fwd, tg, y, (int)blockIdx.x);
+            if (y < tg.height) {
+                uint32_t sets = 0u;
+                code = box_stretch_code<N>(org, right, up, fwd, tg, y, (int)blockIdx.x, tg.tie_sets ? &sets : nullptr);
+                // (every marked stretch gets a fresh entry: the sets here, 0 from the wave that marks a row it looked at)
+                if (code == 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
+            }
         }
         // rows of wave w in nibbles of s_code[2w] (rows 0..7) and s_code[2w + 1] (rows 8..15); R == 32: s_code[4w .. 4w + 3]
         uint32_t packed = code << (4 * (lane & 7));
@@ -1127,6 +1219,8 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             while (redo_bits != 0u) {
                 const int rr = __builtin_ctz(redo_bits);
                 redo_bits &= redo_bits - 1u;
+                if (tg.tie_sets && ((uint32_t)(rowcodes >> (4 * rr)) & 15u) != 14u)
+                    tg.tie_sets[((size_t)blockIdx.z * tg.row_count + row0 + rr) * gridDim.x + blockIdx.x] = 0u;
                 atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
             }
         }
@@ -1149,6 +1243,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     dim3 grid;
     grid_for(tg, 64, tg.colors_out ? 4 : 4 * BoxRows<N>::value, li.nframes, grid);
     tg.cull = nullptr;
+    tg.tie_sets = nullptr;
     tg.redo = nullptr;
     tg.cull_words = 0;
     tg.redo_words = 0;
@@ -1178,6 +1273,9 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         const dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + tile_rows - 1) / tile_rows), (unsigned)li.nframes);
         tg.redo_words = ((tg.width + 63) / 64 + 31) / 32;
         tg.redo = li.cull_buf;                        // [frame][row][redo_words], all zero between launches
+        // ... followed by the tie sets of the marked stretches, [frame][row][stretch] dwords (written with the mark)
+        tg.tie_sets = li.cull_buf + (size_t)li.nframes * tg.row_count * tg.redo_words;
+        if (const char *e = getenv("NTRACER_BOX_TIE_SETS")) { if (atoi(e) == 0) tg.tie_sets = nullptr; }        // (A/B)
         // few rows in flight: two waves per redo word
         const long long rwords = (long long)tg.row_count * li.nframes * tg.redo_words;
         int split = rwords < 48 * 1024 ? 2 : 1;                 // (87k words: one wave 3 % faster; 44k: even; 22k: two waves 2 % faster;

@@ -63,6 +63,9 @@ struct NtTarget {
     // box_redo_kernel (a lane needed the reference's own face-by-face arithmetic); cleared by box_cull_kernel
     uint32_t *redo;
     int redo_words;
+    // box_tile_kernel -> box_redo_kernel: for a marked stretch, the faces and coordinates the reference's arithmetic is
+    // needed on, for all its rays (box_stretch_code; 0: work them out ray by ray); [frame][row][stretch] dwords, or nullptr
+    uint32_t *tie_sets;
     // BoxScene tile kernel: per owned row (index = owned-row number; 64 entries of padding) 16 bytes {float sy = fovI*(y -
     // half_h); uint32 y < height; int64 byte offset of the row within a frame}, read with scalar loads; or nullptr
     const void *rowtab;
