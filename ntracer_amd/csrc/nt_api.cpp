@@ -90,6 +90,7 @@ struct DeviceState {
     DevBuf cull;                         // BoxScene: row culling bits
     bool cull_clean = false;             // `cull` is all zero (what the fused BoxScene path needs and leaves behind)
     DevBuf checked;                      // reference-faithful normals: the exact `checked` bitmap, one column per resident lane
+    DevBuf ties;                         // BoxScene: tie sets of the marked stretches (fused path)
     DevBuf tframes;                      // run-time-n transparency kernel: the ray_color frame stacks, one column per resident lane
     // camera tables travel through pinned host memory (a pageable source makes hipMemcpyAsync wait for the copy on the
     // host, which stalls the launch pipeline of back-to-back calls): a ring of slots, each guarded by an event
@@ -599,6 +600,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
     li.numer_buf = nullptr;
     li.numer_frames = 0;
     li.cull_buf = nullptr;
+    li.tie_buf = nullptr;
     li.cull_clean = 0;
     li.box_path = 1;
     if (const char *bp = getenv("NTRACER_BOX_PATH")) li.box_path = atoi(bp);
@@ -728,9 +730,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             const size_t words = (size_t)(((tg.width + 63) / 64 + 31) / 32);
             // stretch codes (4 words per redo word), 16 rows of padding (box_kernel reads a wave's rows without
             // clamping), redo bits
-            // (the fused kernels: redo bits, then one dword per stretch for the tie sets)
-            const size_t need = std::max(((size_t)5 * job.nframes * tg.row_count + 64) * words * sizeof(uint32_t),
-                                         (size_t)job.nframes * tg.row_count * (words + (size_t)((tg.width + 63) / 64)) * sizeof(uint32_t));
+            const size_t need = ((size_t)5 * job.nframes * tg.row_count + 64) * words * sizeof(uint32_t);
             if (need > ds->cull.cap || !ds->cull.p) ds->cull_clean = false;
             if (int e = ds->cull.ensure(need)) return e;
             // The fused kernels keep their redo bitmap at the start of this buffer and leave it zeroed; after anything else
@@ -748,6 +748,8 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             li.cull_buf = (uint32_t *)ds->cull.p;
             if (fused) {
                 if (int e = row_table(ds, tg, tg.rowtab)) return e;
+                if (int e = ds->ties.ensure((size_t)job.nframes * tg.row_count * ((tg.width + 63) / 64) * sizeof(uint32_t))) return e;
+                li.tie_buf = (uint32_t *)ds->ties.p;
             }
         }
         r = nt_launch_box(li, cam, tg);
@@ -924,7 +926,7 @@ void nt_scene_destroy(nt_scene_t *s) {
         (void)hipDeviceSynchronize();
         for (DevBuf *b : {&ds->nodes, &ds->items, &ds->batch_recs, &ds->batch_mats, &ds->tri_recs, &ds->tri_mats, &ds->solid_recs,
                           &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams, &ds->counter,
-                          &ds->probes, &ds->stats, &ds->hits, &ds->numer, &ds->cull, &ds->checked, &ds->tframes})
+                          &ds->probes, &ds->stats, &ds->hits, &ds->numer, &ds->cull, &ds->checked, &ds->tframes, &ds->ties})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
         for (auto &t : ds->row_tables) if (t->dev) (void)hipFree(t->dev);

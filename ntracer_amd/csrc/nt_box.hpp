@@ -753,14 +753,15 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
 //    box_redo_kernel renders it (its redo bit is set here).
 // Reciprocals are approximate (v_rcp_f32); the slacks above are ~1000x their error.
 // The code of one 64-pixel stretch (see the comment above): row y of the image, stretch `col` of the row.
-// `sets` (box_tile_kernel): for a code-14 stretch, what box_resolve works out ray by ray from entry times -- the faces T that
+// `sets` (box_tile_kernel): for a stretch that may end up with box_redo_kernel (codes 14 and 15), what box_resolve works out ray by ray from entry times -- the faces T that
 // can still be the reference's answer and the coordinates C one of them could fail at -- as supersets valid for EVERY ray
 // of the stretch (bits 0..9: T, bits 10..19: C, bit 31: valid), so that box_redo_kernel goes straight to the reference's
 // arithmetic on them.  With [A_j, B_j] the range of slab j's entry time over the stretch's directions: every ray's last
 // entry is at or after TN = max_j A_j; M = m / (the smallest |v_j| of an axis that can be last, B_j >= TN) is at least the
-// ray's m/|v_K|; so a face within m/|v_K| of a ray's last entry has B_j >= TN - M: that is T.  The entries of T's faces
-// lie in [TN - M, max_j B_j]; a coordinate that stays inside 1 - m over that span of tau, for all the stretch's
-// directions, passes every test made there: the others, and T itself, are C.  No valid sets when a candidate's v_j
+// ray's m/|v_K|; so a face within m/|v_K| of a ray's last entry has B_j >= TN - M: that is T.  The entries of T's faces,
+// for any ray, lie in [min_{T} A_j, max_j B_j]; a coordinate that stays inside 1 - m over that span of tau, for all the
+// stretch's directions, passes every test made there: the others, and T itself, are C.  (A face of T that a given ray
+// enters long before its last entry fails at that ray's last axis, which is in T, hence in C.)  No valid sets when a candidate's v_j
 // changes sign in the stretch or TN - M is not clearly positive (rays starting on or in the cube: box_color's business).
 template <int N>
 __device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], const float (&right)[N], const float (&up)[N], const float (&fwd)[N],
@@ -829,8 +830,8 @@ __device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], cons
         // The middle ray enters two slabs within m/|v_K| of each other: box_classify would call the rays around it
         // unclear and box_kernel would hand the stretch to box_redo_kernel after classifying all of it -- send it
         // there directly (code 14; only a prediction: box_redo_kernel is right for any stretch).
-        if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) {
-            code = 14u;
+        if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) code = 14u;
+        if (code >= 14u) {
             if (sets != nullptr && N <= 10) {
                 float A[N], B[N];
                 float TN = -INFINITY, TH = -INFINITY;
@@ -853,17 +854,24 @@ __device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], cons
                     if (B[j] >= TN) vmin = fminf(vmin, va * vb > 0.0f ? fminf(fabsf(va), fabsf(vb)) : 0.0f);
                 }
                 const float M = m * __builtin_amdgcn_rcpf(vmin) * (1.0f + 1e-5f);
-                const float t_lo = TN - M, t_hi = TH;
+                // T, and the earliest entry of any of its faces for any ray: every test the redo kernel makes is made at a
+                // tau in [t_lo, t_hi]
                 uint32_t T = 0u, C = 0u;
+                float t_lo = INFINITY;
+                const float t_hi = TH;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const bool inT = B[j] >= TN - M;
+                    T |= inT ? 1u << j : 0u;
+                    t_lo = inT ? fminf(t_lo, A[j]) : t_lo;
+                }
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const float va = vc[j] - g[j], vb = vc[j] + g[j];
-                    const bool inT = B[j] >= t_lo;
                     const float pmax = org[j] + fmaxf(vb * t_lo, vb * t_hi);
                     const float pmin = org[j] + fminf(va * t_lo, va * t_hi);
                     const float lim = 1.0f - m - 1e-4f;
-                    const bool inC = inT || !(pmax <= lim && pmin >= -lim);
-                    T |= inT ? 1u << j : 0u;
+                    const bool inC = ((T >> j) & 1u) != 0u || !(pmax <= lim && pmin >= -lim);
                     C |= inC ? 1u << j : 0u;
                 }
                 const bool valid = vmin > 0.0f && t_lo > 1e-3f && t_hi < 1e30f;         // (a NaN fails)
@@ -961,7 +969,7 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 uint32_t sets = 0u;
                 code = box_stretch_code<N>(org, right, up, fwd, tg, y, (int)blockIdx.x, tg.tie_sets ? &sets : nullptr);
                 // (every marked stretch gets a fresh entry: the sets here, 0 from the wave that marks a row it looked at)
-                if (code == 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
+                if (code >= 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
             }
         }
         // rows of wave w in nibbles of s_code[2w] (rows 0..7) and s_code[2w + 1] (rows 8..15); R == 32: s_code[4w .. 4w + 3]
@@ -1219,7 +1227,7 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             while (redo_bits != 0u) {
                 const int rr = __builtin_ctz(redo_bits);
                 redo_bits &= redo_bits - 1u;
-                if (tg.tie_sets && ((uint32_t)(rowcodes >> (4 * rr)) & 15u) != 14u)
+                if (tg.tie_sets && ((uint32_t)(rowcodes >> (4 * rr)) & 15u) < 14u)
                     tg.tie_sets[((size_t)blockIdx.z * tg.row_count + row0 + rr) * gridDim.x + blockIdx.x] = 0u;
                 atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
             }
@@ -1273,8 +1281,10 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         const dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + tile_rows - 1) / tile_rows), (unsigned)li.nframes);
         tg.redo_words = ((tg.width + 63) / 64 + 31) / 32;
         tg.redo = li.cull_buf;                        // [frame][row][redo_words], all zero between launches
-        // ... followed by the tie sets of the marked stretches, [frame][row][stretch] dwords (written with the mark)
-        tg.tie_sets = li.cull_buf + (size_t)li.nframes * tg.row_count * tg.redo_words;
+        // the tie sets of the marked stretches, [frame][row][stretch] dwords (written with the mark)
+        // (a buffer of their own: the bitmap's buffer must hold nothing but the bitmap, which has to be all zero whatever the
+        // next launch's geometry is)
+        tg.tie_sets = li.tie_buf;
         if (const char *e = getenv("NTRACER_BOX_TIE_SETS")) { if (atoi(e) == 0) tg.tie_sets = nullptr; }        // (A/B)
         // few rows in flight: two waves per redo word
         const long long rwords = (long long)tg.row_count * li.nframes * tg.redo_words;

@@ -159,6 +159,7 @@ struct NtLaunchInfo {
     int numer_frames;
     int box_path;             // BoxScene: 1 = fused tile kernel for the scripted formats (default), 0 = cull / box / redo kernels
     int cull_clean;           // cull_buf is all zero (the fused path's redo bitmap lives at its start)
+    uint32_t *tie_buf;        // BoxScene: scratch for the tie sets of the fused path, nframes * row_count * ceil(width/64) dwords (or nullptr)
     uint32_t *cull_buf;       // BoxScene: scratch for the row culling bits, 5 * nframes * row_count * ceil(ceil(width/64)/32) dwords: stretch codes, then redo bits (or nullptr)
 };
 
