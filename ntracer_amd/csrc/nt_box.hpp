@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
 #pragma unroll
         for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
         uint32_t sets = 0u;
-        if (tg.tie_sets) {
+        if (N <= 8 && tg.tie_sets) {
             const int stretch = (int)blockIdx.x * 32 + bit;
             sets = (uint32_t)__builtin_amdgcn_readfirstlane((int)tg.tie_sets[((size_t)blockIdx.z * tg.row_count + row) * ((tg.width + 63) / 64) + stretch]);
         }
@@ -763,9 +763,12 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
 // stretch's directions, passes every test made there: the others, and T itself, are C.  (A face of T that a given ray
 // enters long before its last entry fails at that ray's last axis, which is in T, hence in C.)  No valid sets when a candidate's v_j
 // changes sign in the stretch or TN - M is not clearly positive (rays starting on or in the cube: box_color's business).
-template <int N>
-__device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], const float (&right)[N], const float (&up)[N], const float (&fwd)[N],
-                                                     const NtTarget &tg, int y, int col, uint32_t *sets = nullptr) {
+template <int N, bool SETS = false>
+__device__ __forceinline__ unsigned long long box_stretch_code2(const float (&org)[N], const float (&right)[N], const float (&up)[N],
+                                                                const float (&fwd)[N], const NtTarget &tg, int y, int col) {
+    // returns the code in the low dword and, SETS, the sets in the high one
+    uint32_t sets_value = 0u;
+    uint32_t *const sets = SETS ? &sets_value : nullptr;
     uint32_t code = 0u;
     float omax = fabsf(org[0]);
 #pragma unroll
@@ -833,25 +836,32 @@ __device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], cons
         if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) code = 14u;
         if (code >= 14u) {
             if (sets != nullptr && N <= 10) {
-                float A[N], B[N];
-                float TN = -INFINITY, TH = -INFINITY;
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
+                // (the ranges are worked out anew in each of the three passes rather than kept: this is a rare path, and 2N more
+                // live registers would set the whole kernel's allocation)
+                auto range = [&](int j, float &A, float &B, float &vabs) {
                     const float va = vc[j] - g[j], vb = vc[j] + g[j];
                     const float num = (vc[j] < 0.0f ? 1.0f : -1.0f) - org[j];
                     const float e1 = num * __builtin_amdgcn_rcpf(va), e2 = num * __builtin_amdgcn_rcpf(vb);
                     const float lo = fminf(e1, e2), hi = fmaxf(e1, e2);
                     const bool same = va * vb > 0.0f;
-                    A[j] = same ? lo - fabsf(lo) * 1e-6f : -INFINITY;          // (v_rcp_f32: 1 ulp)
-                    B[j] = same ? hi + fabsf(hi) * 1e-6f : INFINITY;
-                    TN = fmaxf(TN, A[j]);
-                    TH = fmaxf(TH, B[j]);
+                    A = same ? lo - fabsf(lo) * 1e-6f : -INFINITY;             // (v_rcp_f32: 1 ulp)
+                    B = same ? hi + fabsf(hi) * 1e-6f : INFINITY;
+                    vabs = same ? fminf(fabsf(va), fabsf(vb)) : 0.0f;
+                };
+                float TN = -INFINITY, TH = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    float A, B, va_;
+                    range(j, A, B, va_);
+                    TN = fmaxf(TN, A);
+                    TH = fmaxf(TH, B);
                 }
                 float vmin = INFINITY;                  // the smallest |v_j| an axis that can be last has anywhere in the stretch
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const float va = vc[j] - g[j], vb = vc[j] + g[j];
-                    if (B[j] >= TN) vmin = fminf(vmin, va * vb > 0.0f ? fminf(fabsf(va), fabsf(vb)) : 0.0f);
+                    float A, B, va_;
+                    range(j, A, B, va_);
+                    if (B >= TN) vmin = fminf(vmin, va_);
                 }
                 const float M = m * __builtin_amdgcn_rcpf(vmin) * (1.0f + 1e-5f);
                 // T, and the earliest entry of any of its faces for any ray: every test the redo kernel makes is made at a
@@ -861,9 +871,11 @@ __device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], cons
                 const float t_hi = TH;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const bool inT = B[j] >= TN - M;
+                    float A, B, va_;
+                    range(j, A, B, va_);
+                    const bool inT = B >= TN - M;
                     T |= inT ? 1u << j : 0u;
-                    t_lo = inT ? fminf(t_lo, A[j]) : t_lo;
+                    t_lo = inT ? fminf(t_lo, A) : t_lo;
                 }
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
@@ -879,7 +891,12 @@ __device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], cons
             }
         }
     }
-    return code;
+    return (unsigned long long)code | ((unsigned long long)sets_value << 32);
+}
+template <int N>
+__device__ __forceinline__ uint32_t box_stretch_code(const float (&org)[N], const float (&right)[N], const float (&up)[N], const float (&fwd)[N],
+                                                     const NtTarget &tg, int y, int col) {
+    return (uint32_t)box_stretch_code2<N, false>(org, right, up, fwd, tg, y, col);
 }
 
 template <int N>
@@ -966,10 +983,13 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 y = (band * tg.band_world + tg.band_rank) * tg.band_rows + (orow - band * tg.band_rows);
             }
             if (y < tg.height) {
-                uint32_t sets = 0u;
-                code = box_stretch_code<N>(org, right, up, fwd, tg, y, (int)blockIdx.x, tg.tie_sets ? &sets : nullptr);
+                // (N > 8: the sets' arithmetic would raise the kernel's register allocation -- 124 VGPRs and spills at N = 10 --
+                // for every row; those dimensions go without)
+                const unsigned long long cs = box_stretch_code2<N, (N <= 8)>(org, right, up, fwd, tg, y, (int)blockIdx.x);
+                code = (uint32_t)cs;
+                const uint32_t sets = (uint32_t)(cs >> 32);
                 // (every marked stretch gets a fresh entry: the sets here, 0 from the wave that marks a row it looked at)
-                if (code >= 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
+                if (N <= 8 && code >= 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
             }
         }
         // rows of wave w in nibbles of s_code[2w] (rows 0..7) and s_code[2w + 1] (rows 8..15); R == 32: s_code[4w .. 4w + 3]
@@ -1227,7 +1247,7 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             while (redo_bits != 0u) {
                 const int rr = __builtin_ctz(redo_bits);
                 redo_bits &= redo_bits - 1u;
-                if (tg.tie_sets && ((uint32_t)(rowcodes >> (4 * rr)) & 15u) < 14u)
+                if (N <= 8 && tg.tie_sets && ((uint32_t)(rowcodes >> (4 * rr)) & 15u) < 14u)
                     tg.tie_sets[((size_t)blockIdx.z * tg.row_count + row0 + rr) * gridDim.x + blockIdx.x] = 0u;
                 atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
             }
@@ -1284,7 +1304,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         // the tie sets of the marked stretches, [frame][row][stretch] dwords (written with the mark)
         // (a buffer of their own: the bitmap's buffer must hold nothing but the bitmap, which has to be all zero whatever the
         // next launch's geometry is)
-        tg.tie_sets = li.tie_buf;
+        tg.tie_sets = N <= 8 ? li.tie_buf : nullptr;
         if (const char *e = getenv("NTRACER_BOX_TIE_SETS")) { if (atoi(e) == 0) tg.tie_sets = nullptr; }        // (A/B)
         // few rows in flight: two waves per redo word
         const long long rwords = (long long)tg.row_count * li.nframes * tg.redo_words;
