@@ -309,13 +309,17 @@ __device__ __forceinline__ float sqrt_wave(float x) {
 template <int N, bool PLAIN, bool DEFER = false, bool REDO = false, bool F32 = false>
 __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
                                           const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true, int face = -1,
-                                          uint32_t sets = 0u) {
+                                          uint32_t sets = 0u, bool noclass = false) {
+    // noclass (wave-uniform; box_tile_kernel<F32 = true> only, which has no second kernel): a near-tie stretch (code 14) --
+    // as in box_redo_kernel, no sorting into clear and unclear first
+    constexpr bool INL = F32 && !REDO && !DEFER;
+    const bool redo = REDO || (INL && noclass);
     // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
     // face (wave-uniform) >= 0: every ray of the stretch is known to hit that face (a one-face row of box_tile_kernel whose
     // cheap quantisation came too close to a rounding boundary): nothing to sort, only the exact colour is wanted
     // (DEFER: the callers pass the code of the stretch as rowhit -- a stretch that survived the codes wave is next to the
     // cube, where the circumsphere test rarely spares a wave the classification and costs eight instructions every time)
-    const bool maybe = REDO || (rowhit && (DEFER || box_may_hit(N, dots, sx, sy, sq)));
+    const bool maybe = redo || (rowhit && (DEFER || INL || box_may_hit(N, dots, sx, sy, sq)));
     float r, g, b;
     bool hit = false, unclear = false;
     float x = dir[0];
@@ -325,7 +329,7 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
         hit = true;
 #pragma unroll
         for (int j = 1; j < N; ++j) x = face == j ? dir[j] : x;
-    } else if (REDO && (sets & 0x80000000u) != 0u) {
+    } else if ((REDO || INL) && redo && (sets & 0x80000000u) != 0u) {
         // sets (wave-uniform, box_redo_kernel): T and C of the whole stretch from the codes wave (box_stretch_code) -- the
         // reference's arithmetic on them, as in box_resolve, without the entry times
         const float len = sqrt_wave(sq);
@@ -357,7 +361,7 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
                 }
             }
         }
-    } else if (REDO) {
+    } else if (redo) {
         box_entries<N>(org, dir, near, tn, vK);
         unclear = true;
     } else if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
@@ -953,6 +957,10 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
     static_assert(WAVES >= 1 && WAVES <= 4 && WAVES * ROWS <= 64, "the codes of a tile are the work of one wave, a row per lane");
     constexpr int R = ROWS;
     __shared__ uint32_t s_code[64];
+    // F32: this kernel is bound by its stores (12 bytes a pixel), not by vector instructions, and renders the near-tie and
+    // unclear stretches itself -- no second kernel; the tie sets of its rows stay in LDS
+    constexpr bool SETS_LDS = F32 && N <= 8;
+    __shared__ uint32_t s_sets[SETS_LDS ? 64 : 1];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -974,6 +982,7 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
     // the extra work does not always land on the same SIMD of a CU
     if (wv == (int)((blockIdx.x + blockIdx.y + blockIdx.z) % (unsigned)WAVES)) {
         uint32_t code = 0u;
+        uint32_t row_sets = 0u;
         const int trow = tile_row0 + lane;
         if (lane < WAVES * R && trow < tg.row_count) {
             const int orow = tg.row_begin + trow;
@@ -989,9 +998,11 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 code = (uint32_t)cs;
                 const uint32_t sets = (uint32_t)(cs >> 32);
                 // (every marked stretch gets a fresh entry: the sets here, 0 from the wave that marks a row it looked at)
-                if (N <= 8 && code >= 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
+                row_sets = sets;
+                if (!F32 && N <= 8 && code >= 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
             }
         }
+        if (SETS_LDS) s_sets[lane] = row_sets;
         // rows of wave w in nibbles of s_code[2w] (rows 0..7) and s_code[2w + 1] (rows 8..15); R == 32: s_code[4w .. 4w + 3]
         uint32_t packed = code << (4 * (lane & 7));
         packed |= (uint32_t)__shfl_xor((int)packed, 1, 64);
@@ -1081,8 +1092,8 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
         const unsigned long long nc = rowcodes;
         const unsigned long long nz = (nc | (nc >> 1) | (nc >> 2) | (nc >> 3)) & nib;            // code != 0
         const unsigned long long hi3 = ((nc >> 1) & (nc >> 2) & (nc >> 3)) & nib;                // code is 14 or 15
-        unsigned long long quick = validn & ~nz, todo = validn & hi3 & nc, inner = validn & nz & ~hi3;
-        {
+        unsigned long long quick = validn & ~nz, todo = validn & hi3 & (F32 ? ~0ull : nc), inner = validn & nz & ~hi3;
+        if (!F32) {
             unsigned long long skip = validn & hi3 & ~nc;                                        // code 14: not looked at here
             while (skip != 0ull) {
                 redo_bits |= 1u << (__builtin_ctzll(skip) >> 2);
@@ -1239,11 +1250,19 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
             // (a row with a face code is here because its cheap quantisation failed: the face is known)
             const int rcode = (int)((uint32_t)(rowcodes >> (4 * rr)) & 15u);
-            if (!box_pixel<N, !F32, true, false, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit, rcode >= 1 && rcode <= 13 ? rcode - 1 : -1))
+            if (F32) {
+                // everything here: classification, the reference's arithmetic on the faces in question (on the stretch's tie sets
+                // for a near-tie stretch), box_color for rays that start on or in the cube
+                uint32_t sets = 0u;
+                if (SETS_LDS) sets = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sets[wv * R + 16 * half + rr]);
+                box_pixel<N, false, false, false, true>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit, rcode >= 1 && rcode <= 13 ? rcode - 1 : -1, sets,
+                                                         rcode == 14);
+            } else if (!box_pixel<N, true, true, false, false>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit, rcode >= 1 && rcode <= 13 ? rcode - 1 : -1)) {
                 redo_bits |= 1u << rr;
+            }
         }
         // mark the rows left over in the redo bitmap (clean on entry: box_redo_kernel zeroes what it has read)
-        if (lane == 0) {
+        if (!F32 && lane == 0) {
             while (redo_bits != 0u) {
                 const int rr = __builtin_ctz(redo_bits);
                 redo_bits &= redo_bits - 1u;
@@ -1325,8 +1344,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
             else if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
             else if (r16) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 4>), tgrid, dim3(256), 0, st, cf, tg);
             else hipLaunchKernelGGL((box_tile_kernel<N, true, 8, 4>), tgrid, dim3(256), 0, st, cf, tg);
-            if (split == 2) hipLaunchKernelGGL((box_redo_kernel<N, true, true, 2>), rgrid, dim3(256), 0, st, cf, tg);
-            else hipLaunchKernelGGL((box_redo_kernel<N, true, true, 1>), rgrid, dim3(256), 0, st, cf, tg);
+            // (no second kernel: bound by its stores, the tile kernel has the vector instructions to spare)
         }
         return 0;
     }
