@@ -767,6 +767,17 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
 // stretch's directions, passes every test made there: the others, and T itself, are C.  (A face of T that a given ray
 // enters long before its last entry fails at that ray's last axis, which is in T, hence in C.)  No valid sets when a candidate's v_j
 // changes sign in the stretch or TN - M is not clearly positive (rays starting on or in the cube: box_color's business).
+// v_max_f32 / v_min_f32 as they are: fmaxf / fminf on a value that reaches them from another basic block come with a
+// canonicalising `v_max_f32 x, x, x` per operand (the compiler cannot see that the value is the result of arithmetic), and
+// these instructions run at half the rate of a multiply: an eighth of box_stretch_code's instructions were such no-ops.
+// Quiet NaNs drop out of the hardware's max / min as they do out of fmaxf / fminf; every operand here is the result of
+// arithmetic or an infinity.
+__device__ __forceinline__ float nt_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float nt_vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float nt_vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float nt_vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float nt_vmed3(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 template <int N, bool SETS = false>
 __device__ __forceinline__ unsigned long long box_stretch_code2(const float (&org)[N], const float (&right)[N], const float (&up)[N],
                                                                 const float (&fwd)[N], const NtTarget &tg, int y, int col) {
@@ -783,7 +794,6 @@ __device__ __forceinline__ unsigned long long box_stretch_code2(const float (&or
     const float sy = tg.fovI * ((float)y - tg.half_h);
     const float spread = 32.0f * tg.fovI;
     float tlo = 0.0f, thi = INFINITY;
-    bool dead = false;
     float vc[N], g[N];
     float tn = -INFINITY, tn2 = -INFINITY, vK = 0.0f, gK = 0.0f, oK = 0.0f;
     int K = 0;
@@ -794,42 +804,45 @@ __device__ __forceinline__ unsigned long long box_stretch_code2(const float (&or
         const float pa = vc[j] + g[j], qa = -h - org[j];
         const float pb = vc[j] - g[j], qb = h - org[j];
         const float ra = qa * __builtin_amdgcn_rcpf(pa), rb = qb * __builtin_amdgcn_rcpf(pb);
-        // pa*tau >= qa bounds tau from below when pa > 0, from above when pa < 0; pb*tau <= qb the other way round
-        // (a NaN -- 0*inf -- drops out of fmaxf / fminf)
-        const float lo_a = pa > 0.0f ? ra : -INFINITY, hi_a = pa < 0.0f ? ra : INFINITY;
-        const float hi_b = pb > 0.0f ? rb : INFINITY, lo_b = pb < 0.0f ? rb : -INFINITY;
-        tlo = fmaxf(tlo, fmaxf(lo_a, lo_b));
-        thi = fminf(thi, fminf(hi_a, hi_b));
-        dead = dead || (pa == 0.0f && qa > 0.0f) || (pb == 0.0f && qb < 0.0f);
+        // pa*tau >= qa bounds tau from below when pa > 0, from above when pa < 0; pb*tau <= qb the other way round.  A zero
+        // (always +0: g > 0, and x + y is -0 only for two negative zeros) goes with the positive side: ra is then
+        // -inf (no bound), +inf (qa > 0: no tau at all -- tlo = inf) or a NaN, 0*inf, which drops out of max / min
+        const bool ap = pa >= 0.0f, bp = pb >= 0.0f;
+        const float lo_a = ap ? ra : -INFINITY, hi_a = ap ? INFINITY : ra;
+        const float hi_b = bp ? rb : INFINITY, lo_b = bp ? -INFINITY : rb;
+        tlo = nt_vmax3(tlo, lo_a, lo_b);
+        thi = nt_vmin3(thi, hi_a, hi_b);
     }
-    if (!(dead || tlo > thi)) {                      // a NaN keeps the stretch
+    if (!(tlo > thi)) {                              // a NaN keeps the stretch
         code = 15u;
         // the middle ray's entries into the slabs: the last one, K, and the one before it (any K is verified below, so
         // accuracy only matters for the yield).  Only for stretches that survive: most tiles have none.
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const float nr = ((vc[j] < 0.0f ? 1.0f : -1.0f) - org[j]) * __builtin_amdgcn_rcpf(vc[j]);
-            tn2 = __builtin_amdgcn_fmed3f(tn, tn2, nr);         // second-to-last entry
+            tn2 = nt_vmed3(tn, tn2, nr);                        // second-to-last entry
             const bool later = nr > tn;
             vK = later ? vc[j] : vK;
             gK = later ? g[j] : gK;
             oK = later ? org[j] : oK;
             K = later ? j : K;
-            tn = fmaxf(tn, nr);
+            tn = nt_vmax(tn, nr);
         }
         const float vKa = vK - gK, vKb = vK + gK;
         if (N <= 14 && vKa * vKb > 0.0f) {
             const float num = (vK < 0.0f ? 1.0f : -1.0f) - oK;
             const float t1 = num * __builtin_amdgcn_rcpf(vKa), t2 = num * __builtin_amdgcn_rcpf(vKb);
-            const float t_lo = fminf(t1, t2) * (1.0f - 1e-6f), t_hi = fmaxf(t1, t2) * (1.0f + 1e-6f);
-            const float rK = m * __builtin_amdgcn_rcpf(fminf(fabsf(vKa), fabsf(vKb))) * (1.0f + 1e-6f);
+            const float t_lo = nt_vmin(t1, t2) * (1.0f - 1e-6f), t_hi = nt_vmax(t1, t2) * (1.0f + 1e-6f);
+            // (the smaller of |vKa|, |vKb| with both of one sign: |vK| - gK, rounded the same way)
+            const float rK = m * __builtin_amdgcn_rcpf(fabsf(vK) - gK) * (1.0f + 1e-6f);
             bool ok = t_lo > 1e-3f && t_hi < 1e30f;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const float va = vc[j] - g[j], vb = vc[j] + g[j];
-                const float pmax = org[j] + fmaxf(vb * t_lo, vb * t_hi);
-                const float pmin = org[j] + fminf(va * t_lo, va * t_hi);
-                const float lim = (1.0f - m - 1e-4f) - fmaxf(fabsf(va), fabsf(vb)) * rK;
+                const float pmax = org[j] + nt_vmax(vb * t_lo, vb * t_hi);
+                const float pmin = org[j] + nt_vmin(va * t_lo, va * t_hi);
+                // (the larger of |va|, |vb| is |vc| + g, rounded the same way)
+                const float lim = (1.0f - m - 1e-4f) - (fabsf(vc[j]) + g[j]) * rK;
                 ok = ok && (j == K || (pmax <= lim && pmin >= -lim));
             }
             if (ok) code = (uint32_t)K + 1u;
@@ -846,26 +859,26 @@ __device__ __forceinline__ unsigned long long box_stretch_code2(const float (&or
                     const float va = vc[j] - g[j], vb = vc[j] + g[j];
                     const float num = (vc[j] < 0.0f ? 1.0f : -1.0f) - org[j];
                     const float e1 = num * __builtin_amdgcn_rcpf(va), e2 = num * __builtin_amdgcn_rcpf(vb);
-                    const float lo = fminf(e1, e2), hi = fmaxf(e1, e2);
+                    const float lo = nt_vmin(e1, e2), hi = nt_vmax(e1, e2);
                     const bool same = va * vb > 0.0f;
                     A = same ? lo - fabsf(lo) * 1e-6f : -INFINITY;             // (v_rcp_f32: 1 ulp)
                     B = same ? hi + fabsf(hi) * 1e-6f : INFINITY;
-                    vabs = same ? fminf(fabsf(va), fabsf(vb)) : 0.0f;
+                    vabs = same ? fabsf(vc[j]) - g[j] : 0.0f;                  // (the smaller of |va|, |vb|)
                 };
                 float TN = -INFINITY, TH = -INFINITY;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     float A, B, va_;
                     range(j, A, B, va_);
-                    TN = fmaxf(TN, A);
-                    TH = fmaxf(TH, B);
+                    TN = nt_vmax(TN, A);
+                    TH = nt_vmax(TH, B);
                 }
                 float vmin = INFINITY;                  // the smallest |v_j| an axis that can be last has anywhere in the stretch
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     float A, B, va_;
                     range(j, A, B, va_);
-                    if (B >= TN) vmin = fminf(vmin, va_);
+                    vmin = B >= TN ? nt_vmin(vmin, va_) : vmin;
                 }
                 const float M = m * __builtin_amdgcn_rcpf(vmin) * (1.0f + 1e-5f);
                 // T, and the earliest entry of any of its faces for any ray: every test the redo kernel makes is made at a
@@ -879,13 +892,13 @@ __device__ __forceinline__ unsigned long long box_stretch_code2(const float (&or
                     range(j, A, B, va_);
                     const bool inT = B >= TN - M;
                     T |= inT ? 1u << j : 0u;
-                    t_lo = inT ? fminf(t_lo, A) : t_lo;
+                    t_lo = inT ? nt_vmin(t_lo, A) : t_lo;
                 }
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const float va = vc[j] - g[j], vb = vc[j] + g[j];
-                    const float pmax = org[j] + fmaxf(vb * t_lo, vb * t_hi);
-                    const float pmin = org[j] + fminf(va * t_lo, va * t_hi);
+                    const float pmax = org[j] + nt_vmax(vb * t_lo, vb * t_hi);
+                    const float pmin = org[j] + nt_vmin(va * t_lo, va * t_hi);
                     const float lim = 1.0f - m - 1e-4f;
                     const bool inC = ((T >> j) & 1u) != 0u || !(pmax <= lim && pmin >= -lim);
                     C |= inC ? 1u << j : 0u;
@@ -951,8 +964,19 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
 // ROWS x WAVES: 64 x 1 for launches of 512 rows or more with waves to spare (what depends on the column alone is set up once
 // for 64 rows); otherwise 16 (8 in small launches) x 4, or x 3 when that leaves fewer idle waves below the last row of the
 // launch (a rank's 136 rows of a 1080-row frame: three tiles of 48 rows instead of three of 64).
+// (experiment switch: -DNT_EXP_NOSTORE times the tile kernel's lean loops without their stores)
+#ifdef NT_EXP_NOSTORE
+#define NT_EXP_STORE_IF if (tg.width < 0)
+#else
+#define NT_EXP_STORE_IF
+#endif
+// Occupancy: up to six dimensions the packed-RGB kernel is held to 64 VGPRs, eight waves a SIMD instead of seven (69 at N = 6:
+// four dwords of the rarely taken paths go to scratch) -- 1-2 % faster; beyond that the spills would outweigh it.
+#ifndef NT_TILE_OCC
+#define NT_TILE_OCC __attribute__((amdgpu_waves_per_eu((N <= 6 && !F32) ? 8 : 1, 8)))
+#endif
 template <int N, bool F32, int ROWS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
+__global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
     static_assert(ROWS == 8 || ROWS == 16 || ROWS == 32 || ROWS == 64, "sixteen row codes to a qword, one to four qwords a wave");
     static_assert(WAVES >= 1 && WAVES <= 4 && WAVES * ROWS <= 64, "the codes of a tile are the work of one wave, a row per lane");
     constexpr int R = ROWS;
@@ -1063,8 +1087,13 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
             }
             fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
         }
-        const float m2bu = -2.0f * bu;
         const float maxv = (float)tg.plain_maxval;
+        // ... scaled by 1/maxval^2, so that rsq of it is maxval/|dir|: the multiplication by maxval costs three instructions a
+        // wave instead of one a row (three more roundings of 2^-24 each in a budget that had 2.6x room, see the guard)
+        const float inv_maxv2 = 1.0f / (maxv * maxv);
+        const float m2bu = (-2.0f * bu) * inv_maxv2;
+        bb = bb * inv_maxv2;
+        uu = uu * inv_maxv2;
 #pragma unroll 1
         for (int half = 0; half < HALVES; ++half) {
         const int row0 = wrow0 + 16 * half;
@@ -1113,7 +1142,7 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 NT_ROW_LOAD(rr);
                 const float d0 = base[0] - upv[0] * sy;                   // dir[0], bit for bit
                 const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
-                const float t = (fabsf(d0) * __builtin_amdgcn_rsqf(sqa)) * maxv;
+                const float t = fabsf(d0) * __builtin_amdgcn_rsqf(sqa);          // (sqa is |dir|^2 / maxval^2)
                 const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);
                 if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
                     todo |= 1ull << (4 * rr);                                     // a lane too close to a rounding boundary
@@ -1124,13 +1153,21 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                     // 8-bit fields: t + 2^23 has round(t) in its low mantissa byte (t < 255.5; the guard keeps t off the
                     // half-way points, so nearest-even is the reference's rounding), which is the byte v_perm_b32 picks
                     const uint32_t q = __float_as_uint(t + 8388608.0f);
-                    NT_G32(out) = __builtin_amdgcn_perm(d0 > 0.0f ? q : 0u, q, tg.plain_sel);
+                    // (the sign of dir[0] rarely changes within a stretch: the select is skipped when it is + throughout)
+                    uint32_t w;
+                    if (__builtin_amdgcn_ballot_w64(!(d0 > 0.0f)) != 0ull) {
+                        asm volatile("" ::: "memory");              // (keeps this a branch)
+                        w = __builtin_amdgcn_perm(d0 > 0.0f ? q : 0u, q, tg.plain_sel);
+                    } else {
+                        w = __builtin_amdgcn_perm(q, q, tg.plain_sel);
+                    }
+                    NT_EXP_STORE_IF NT_G32(out) = w;
                     continue;
                 }
                 uint32_t q = (uint32_t)(t + 0.5f);
                 q = q < tg.plain_maxval ? q : tg.plain_maxval;
                 const uint32_t w = (d0 > 0.0f ? q : 0u) * tg.plain_mul[0] + q * (tg.plain_mul[1] + tg.plain_mul[2]);      // (emit_plain)
-                NT_G32(out) = tg.reversed ? w : bswap32(w);
+                NT_EXP_STORE_IF NT_G32(out) = tg.reversed ? w : bswap32(w);
             }
             // (the one-face rows of a wave mostly share their face: its component of `base` is picked once)
             uint32_t K0 = 0u;
@@ -1160,7 +1197,7 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 }
                 const float dK = bK - uK * sy;                            // dir[K], bit for bit
                 const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
-                const float t = (fabsf(dK) * __builtin_amdgcn_rsqf(sqa)) * maxv, th = t * 0.5f;
+                const float t = fabsf(dK) * __builtin_amdgcn_rsqf(sqa), th = t * 0.5f;
                 const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f) &&
                                    fabsf(__builtin_amdgcn_fractf(th) - 0.5f) > fmaf(th, 0x1p-18f, 0x1p-18f);
                 if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
@@ -1169,14 +1206,14 @@ __global__ __launch_bounds__(64 * WAVES) void box_tile_kernel(NtCameraFixed cam,
                 }
                 const nt_gptr out = NT_ROW_PTR() + NT_LANE_OFF();
                 if (tg.plain_sel != 0u) {
-                    NT_G32(out) = __builtin_amdgcn_perm(__float_as_uint(t + 8388608.0f), __float_as_uint(th + 8388608.0f), tg.plain_sel);
+                    NT_EXP_STORE_IF NT_G32(out) = __builtin_amdgcn_perm(__float_as_uint(t + 8388608.0f), __float_as_uint(th + 8388608.0f), tg.plain_sel);
                     continue;
                 }
                 uint32_t qr = (uint32_t)(t + 0.5f), qgb = (uint32_t)(th + 0.5f);
                 qr = qr < tg.plain_maxval ? qr : tg.plain_maxval;
                 qgb = qgb < tg.plain_maxval ? qgb : tg.plain_maxval;
                 const uint32_t w = qr * tg.plain_mul[0] + qgb * (tg.plain_mul[1] + tg.plain_mul[2]);
-                NT_G32(out) = tg.reversed ? w : bswap32(w);
+                NT_EXP_STORE_IF NT_G32(out) = tg.reversed ? w : bswap32(w);
             }
         } else {
             // ---- fp32 channels: the stored value IS x / sqrtf(sq), so the reference's sum, square root and division are
