@@ -981,6 +981,10 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     static_assert(WAVES >= 1 && WAVES <= 4 && WAVES * ROWS <= 64, "the codes of a tile are the work of one wave, a row per lane");
     constexpr int R = ROWS;
     __shared__ uint32_t s_code[64];
+    // ... and the same as one bit per tile row and class (culled / one face / ray by ray / near-tie): the row loops are driven by
+    // 32-bit masks of row bits -- two scalar instructions to step, one to index the row table (masks of nibble positions in a
+    // qword cost five and two; the scalar unit is as busy as the vector units in these loops)
+    __shared__ unsigned long long s_rows[4];
     // F32: this kernel is bound by its stores (12 bytes a pixel), not by vector instructions, and renders the near-tie and
     // unclear stretches itself -- no second kernel; the tie sets of its rows stay in LDS
     constexpr bool SETS_LDS = F32 && N <= 8;
@@ -1027,6 +1031,16 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
             }
         }
         if (SETS_LDS) s_sets[lane] = row_sets;
+        {
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(code == 0u), m1 = __builtin_amdgcn_ballot_w64(code >= 1u && code <= 13u),
+                                     m2 = __builtin_amdgcn_ballot_w64(code == 15u), m3 = __builtin_amdgcn_ballot_w64(code == 14u);
+            if (lane == 0) {
+                s_rows[0] = m0;
+                s_rows[1] = m1;
+                s_rows[2] = m2;
+                s_rows[3] = m3;
+            }
+        }
         // rows of wave w in nibbles of s_code[2w] (rows 0..7) and s_code[2w + 1] (rows 8..15); R == 32: s_code[4w .. 4w + 3]
         uint32_t packed = code << (4 * (lane & 7));
         packed |= (uint32_t)__shfl_xor((int)packed, 1, 64);
@@ -1094,6 +1108,13 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
         const float m2bu = (-2.0f * bu) * inv_maxv2;
         bb = bb * inv_maxv2;
         uu = uu * inv_maxv2;
+        // the classes of the wave's rows, a bit per row
+        auto rows_of = [&](int k) {
+            const unsigned long long m = s_rows[k];
+            return (((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m)) >> (wv * R);
+        };
+        const unsigned long long rows_culled = rows_of(0), rows_face = rows_of(1), rows_rays = rows_of(2), rows_tie = rows_of(3);
 #pragma unroll 1
         for (int half = 0; half < HALVES; ++half) {
         const int row0 = wrow0 + 16 * half;
@@ -1112,54 +1133,46 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
         }
         const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < RH && row0 + lane < tg.row_count && ly < tg.height);
         const nt_rowtab tab = (nt_rowtab)tg.rowtab + (tg.row_begin + row0);
-        const unsigned long long nib = 0x1111111111111111ull;
-        unsigned long long validn = valid & 0xffffu;                       // bit rr -> bit 4rr
-        validn = (validn | (validn << 24)) & 0x000000ff000000ffull;
-        validn = (validn | (validn << 12)) & 0x000f000f000f000full;
-        validn = (validn | (validn << 6)) & 0x0303030303030303ull;
-        validn = (validn | (validn << 3)) & nib;
-        const unsigned long long nc = rowcodes;
-        const unsigned long long nz = (nc | (nc >> 1) | (nc >> 2) | (nc >> 3)) & nib;            // code != 0
-        const unsigned long long hi3 = ((nc >> 1) & (nc >> 2) & (nc >> 3)) & nib;                // code is 14 or 15
-        unsigned long long quick = validn & ~nz, todo = validn & hi3 & (F32 ? ~0ull : nc), inner = validn & nz & ~hi3;
-        if (!F32) {
-            unsigned long long skip = validn & hi3 & ~nc;                                        // code 14: not looked at here
-            while (skip != 0ull) {
-                redo_bits |= 1u << (__builtin_ctzll(skip) >> 2);
-                skip &= skip - 1ull;
-            }
-        }
+        // (bit rr <-> row row0 + rr; code 14 -- a near-tie stretch -- is not looked at here unless this kernel is all there is)
+        uint32_t quick = (uint32_t)(rows_culled >> (16 * half)) & valid, inner = (uint32_t)(rows_face >> (16 * half)) & valid;
+        uint32_t todo = (uint32_t)((F32 ? rows_rays | rows_tie : rows_rays) >> (16 * half)) & valid;
+        if (!F32) redo_bits = (uint32_t)(rows_tie >> (16 * half)) & valid;
         if (!F32) {
             // ---- packed RGB: guarded rsq quantisation (see box_kernel<N, true>)
             if (!fastsq) {
                 todo |= quick | inner;
-                quick = 0ull;
-                inner = 0ull;
+                quick = 0u;
+                inner = 0u;
             }
-            while (quick != 0ull) {
-                const int rr = __builtin_ctzll(quick) >> 2;
-                quick &= quick - 1ull;
+            // (the two loops in two copies: 8-bit fields on byte boundaries -- v_perm_b32 packing, tg.plain_sel -- and the rest;
+            // the test is made once here, not once a row)
+            auto lean_rows = [&](auto sel8) {
+            constexpr bool SEL8 = decltype(sel8)::value;
+            while (quick != 0u) {
+                const int rr = __builtin_ctz(quick);
+                quick &= quick - 1u;
                 NT_ROW_LOAD(rr);
                 const float d0 = base[0] - upv[0] * sy;                   // dir[0], bit for bit
                 const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
                 const float t = fabsf(d0) * __builtin_amdgcn_rsqf(sqa);          // (sqa is |dir|^2 / maxval^2)
                 const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f);
                 if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
-                    todo |= 1ull << (4 * rr);                                     // a lane too close to a rounding boundary
+                    todo |= 1u << rr;                                             // a lane too close to a rounding boundary
                     continue;
                 }
                 const nt_gptr out = NT_ROW_PTR() + NT_LANE_OFF();
-                if (tg.plain_sel != 0u) {
+                if (SEL8) {
                     // 8-bit fields: t + 2^23 has round(t) in its low mantissa byte (t < 255.5; the guard keeps t off the
                     // half-way points, so nearest-even is the reference's rounding), which is the byte v_perm_b32 picks
                     const uint32_t q = __float_as_uint(t + 8388608.0f);
                     // (the sign of dir[0] rarely changes within a stretch: the select is skipped when it is + throughout)
                     uint32_t w;
                     if (__builtin_amdgcn_ballot_w64(!(d0 > 0.0f)) != 0ull) {
-                        asm volatile("" ::: "memory");              // (keeps this a branch)
                         w = __builtin_amdgcn_perm(d0 > 0.0f ? q : 0u, q, tg.plain_sel);
+                        asm volatile("" : "+v"(w));                 // (keeps this a branch, and the v_perm_b32 in it)
                     } else {
                         w = __builtin_amdgcn_perm(q, q, tg.plain_sel);
+                        asm volatile("" : "+v"(w));
                     }
                     NT_EXP_STORE_IF NT_G32(out) = w;
                     continue;
@@ -1172,17 +1185,17 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
             // (the one-face rows of a wave mostly share their face: its component of `base` is picked once)
             uint32_t K0 = 0u;
             float bK0 = base[0], uK0 = upv[0];
-            if (inner != 0ull) {
-                K0 = ((uint32_t)(rowcodes >> (__builtin_ctzll(inner) & 60)) & 15u) - 1u;
+            if (inner != 0u) {
+                K0 = ((uint32_t)(rowcodes >> (4 * __builtin_ctz(inner))) & 15u) - 1u;
 #pragma unroll
                 for (int j = 1; j < N; ++j) {
                     bK0 = K0 == (uint32_t)j ? base[j] : bK0;
                     uK0 = K0 == (uint32_t)j ? upv[j] : uK0;
                 }
             }
-            while (inner != 0ull) {
-                const int rr = __builtin_ctzll(inner) >> 2;
-                inner &= inner - 1ull;
+            while (inner != 0u) {
+                const int rr = __builtin_ctz(inner);
+                inner &= inner - 1u;
                 const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
                 NT_ROW_LOAD(rr);
                 float bK = bK0, uK = uK0;
@@ -1201,11 +1214,11 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
                 const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, 0x1p-18f, 0x1p-18f) &&
                                    fabsf(__builtin_amdgcn_fractf(th) - 0.5f) > fmaf(th, 0x1p-18f, 0x1p-18f);
                 if (__builtin_amdgcn_ballot_w64(!clear) != 0ull) {
-                    todo |= 1ull << (4 * rr);
+                    todo |= 1u << rr;
                     continue;
                 }
                 const nt_gptr out = NT_ROW_PTR() + NT_LANE_OFF();
-                if (tg.plain_sel != 0u) {
+                if (SEL8) {
                     NT_EXP_STORE_IF NT_G32(out) = __builtin_amdgcn_perm(__float_as_uint(t + 8388608.0f), __float_as_uint(th + 8388608.0f), tg.plain_sel);
                     continue;
                 }
@@ -1215,13 +1228,16 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
                 const uint32_t w = qr * tg.plain_mul[0] + qgb * (tg.plain_mul[1] + tg.plain_mul[2]);
                 NT_EXP_STORE_IF NT_G32(out) = tg.reversed ? w : bswap32(w);
             }
+            };
+            if (tg.plain_sel != 0u) lean_rows(std::true_type{});
+            else lean_rows(std::false_type{});
         } else {
             // ---- fp32 channels: the stored value IS x / sqrtf(sq), so the reference's sum, square root and division are
             // done as they stand -- but on rows whose code says which x it is, nothing else is
-            while (quick != 0ull) {
+            while (quick != 0u) {
                 // background rows: i = dir[0]; i > 0 ? (i,i,i) : (0,-i,-i) (tracer.hpp:109-113), clamped as channel_value does
-                const int rr = __builtin_ctzll(quick) >> 2;
-                quick &= quick - 1ull;
+                const int rr = __builtin_ctz(quick);
+                quick &= quick - 1u;
                 NT_ROW_LOAD(rr);
 #pragma unroll
                 for (int j = 0; j < N; ++j) dir[j] = base[j] - upv[j] * sy;
@@ -1235,18 +1251,18 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
             }
             uint32_t K0 = 0u;
             float bK0 = base[0], uK0 = upv[0];
-            if (inner != 0ull) {
-                K0 = ((uint32_t)(rowcodes >> (__builtin_ctzll(inner) & 60)) & 15u) - 1u;
+            if (inner != 0u) {
+                K0 = ((uint32_t)(rowcodes >> (4 * __builtin_ctz(inner))) & 15u) - 1u;
 #pragma unroll
                 for (int j = 1; j < N; ++j) {
                     bK0 = K0 == (uint32_t)j ? base[j] : bK0;
                     uK0 = K0 == (uint32_t)j ? upv[j] : uK0;
                 }
             }
-            while (inner != 0ull) {
+            while (inner != 0u) {
                 // one face K throughout: sine = d_K * (-sign d_K) <= 0, shade = -sine (tracer.hpp:105-107)
-                const int rr = __builtin_ctzll(inner) >> 2;
-                inner &= inner - 1ull;
+                const int rr = __builtin_ctz(inner);
+                inner &= inner - 1u;
                 const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
                 NT_ROW_LOAD(rr);
 #pragma unroll
@@ -1269,9 +1285,9 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
                 emit_f32x3_at(tg, NT_ROW_PTR() + NT_LANE_OFF(), shade * 1.0f, shade * 0.5f);
             }
         }
-        while (todo != 0ull) {
-            const int rr = __builtin_ctzll(todo) >> 2;
-            todo &= todo - 1ull;
+        while (todo != 0u) {
+            const int rr = __builtin_ctz(todo);
+            todo &= todo - 1u;
             const bool rowhit = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) != 0u;
             NT_ROW_LOAD(rr);
             PixelRef pr;
