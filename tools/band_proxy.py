@@ -25,8 +25,9 @@ def measure(world, rank, band_rows, steps, warmup, frames=160, n=6, W=1920, H=10
     from ntracer_amd import _lib, tracern
     from ntracer_amd import distributed as ntd
     g = np.load(os.path.join(ROOT, "tests", "golden", "box_n%d_1920x1080.npz" % n))
-    origins = np.ascontiguousarray(g["origins"][:frames], np.float32)
-    axes = np.ascontiguousarray(g["axes"][:frames], np.float32)
+    idx = np.arange(frames) % len(g["origins"])               # (more frames than the rotation has: round again)
+    origins = np.ascontiguousarray(g["origins"][idx], np.float32)
+    axes = np.ascontiguousarray(g["axes"][idx], np.float32)
     scene = tracern.BoxScene(n)
     if f32:
         fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(32, 1, 0, 0, 0, True), ntracer_amd.Channel(32, 0, 1, 0, 0, True),
