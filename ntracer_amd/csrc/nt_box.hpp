@@ -970,10 +970,11 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
 #else
 #define NT_EXP_STORE_IF
 #endif
-// Occupancy: up to six dimensions the packed-RGB kernel is held to 64 VGPRs, eight waves a SIMD instead of seven (69 at N = 6:
-// four dwords of the rarely taken paths go to scratch) -- 1-2 % faster; beyond that the spills would outweigh it.
+// Occupancy (-DNT_TILE_OCC=...): holding the packed-RGB kernel to 64 VGPRs -- eight waves a SIMD instead of seven at N = 6,
+// `__attribute__((amdgpu_waves_per_eu(8, 8)))` -- was 1 % faster, but the six dwords a lane it spills are 125 MB of scratch
+// traffic a call (HBM bytes 1.16x the framebuffers instead of 1.03x) and 9 % more vector instructions: not taken.
 #ifndef NT_TILE_OCC
-#define NT_TILE_OCC __attribute__((amdgpu_waves_per_eu((N <= 6 && !F32) ? 8 : 1, 8)))
+#define NT_TILE_OCC
 #endif
 template <int N, bool F32, int ROWS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
