@@ -17,6 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libntracer_hip.so")
 DIMS = range(3, 11)
+BOX_ONLY_DIMS = range(11, 17)         # BoxScene kernels alone are also compiled for N = 11..16
 HDR = [os.path.join(CSRC, h) for h in ("nt_device.hpp", "nt_pixel.hpp", "nt_box.hpp", "nt_composite.hpp")] + \
       [os.path.join(HERE, "..", "include", "ntracer_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-fno-slp-vectorize", "-Wall",
@@ -31,6 +32,8 @@ def units():
     for n in DIMS:
         u.append(("nt_box_%d" % n, "nt_inst_box.hip", ["-DNT_INST_N=%d" % n]))
         u.append(("nt_composite_%d" % n, "nt_inst_composite.hip", ["-DNT_INST_N=%d" % n]))
+    for n in BOX_ONLY_DIMS:
+        u.append(("nt_box_%d" % n, "nt_inst_box.hip", ["-DNT_INST_N=%d" % n]))
     return u
 
 

@@ -736,7 +736,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             // The fused kernels keep their redo bitmap at the start of this buffer and leave it zeroed; after anything else
             // has written there (a fresh allocation, the cull / box / redo kernels) it is zeroed here, in stream order.
             // (the formats launch_box_fixed sends there: plain RGB of <= 10 bits in one aligned dword, or three plain fp32 channels)
-            const bool fused = li.box_path != 0 && s->n <= NT_MAX_FIXED_DIM && tg.aligned4 &&
+            const bool fused = li.box_path != 0 && s->n <= NT_MAX_FIXED_BOX_DIM && tg.aligned4 &&
                                ((tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4) || (tg.plain_f32[0] >= 0 && tg.bpp == 12));
             if (fused && !ds->cull_clean) {
                 HIP_TRY(hipMemsetAsync(ds->cull.p, 0, ds->cull.cap, job.stream));

@@ -444,7 +444,7 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
 #ifndef NT_BOXROWS
 #define NT_BOXROWS 8
 #endif
-template <int N> struct BoxRows { static constexpr int value = N <= 10 ? NT_BOXROWS : 1; };
+template <int N> struct BoxRows { static constexpr int value = N <= 16 ? NT_BOXROWS : 1; };
 template <int N, bool PLAIN, int ROWS = BoxRows<N>::value>
 __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg) {
     const int tid = (int)threadIdx.x;
@@ -829,7 +829,7 @@ __device__ __forceinline__ unsigned long long box_stretch_code2(const float (&or
             tn = nt_vmax(tn, nr);
         }
         const float vKa = vK - gK, vKb = vK + gK;
-        if (N <= 14 && vKa * vKb > 0.0f) {
+        if (K < 13 && vKa * vKb > 0.0f) {            // (the code of a one-face stretch is K + 1 <= 13: 14 and 15 are taken; faces 13..15 of N > 13 go without)
             const float num = (vK < 0.0f ? 1.0f : -1.0f) - oK;
             const float t1 = num * __builtin_amdgcn_rcpf(vKa), t2 = num * __builtin_amdgcn_rcpf(vKb);
             const float t_lo = nt_vmin(t1, t2) * (1.0f - 1e-6f), t_hi = nt_vmax(t1, t2) * (1.0f + 1e-6f);

@@ -5,6 +5,7 @@
 
 #define NT_DEV_MAX_DIM 64
 #define NT_DEV_MAX_FIXED 10
+#define NT_DEV_MAX_FIXED_BOX 16        // BoxScene kernels are also compiled for N = 11..16
 #define NT_DEV_BATCH 4
 #define NT_DEV_MAX_REFLECT 16
 
@@ -87,7 +88,7 @@ struct NtCameraFixed {        // N <= 8: 4*8 floats inline
     const float *buf;
     int n;
     float odots[4];
-    float inl[4 * NT_DEV_MAX_FIXED];
+    float inl[4 * NT_DEV_MAX_FIXED_BOX];
 };
 
 struct NtNode {               // 16-byte k-d node record

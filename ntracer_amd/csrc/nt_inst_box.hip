@@ -1,5 +1,5 @@
 // nt_inst_box.hip -- instantiates the BoxScene kernels of nt_box.hpp.  The build compiles this file once per dimension
-// (-DNT_INST_N=3 .. 10, in parallel); without the macro every dimension is instantiated here.
+// (-DNT_INST_N=3 .. 16, in parallel); without the macro every dimension is instantiated here.
 #include "nt_box.hpp"
 
 #define NT_DEFINE_BOX(N) \
@@ -10,4 +10,5 @@
 NT_DEFINE_BOX_(NT_INST_N)
 #else
 NT_DEFINE_BOX(3) NT_DEFINE_BOX(4) NT_DEFINE_BOX(5) NT_DEFINE_BOX(6) NT_DEFINE_BOX(7) NT_DEFINE_BOX(8) NT_DEFINE_BOX(9) NT_DEFINE_BOX(10)
+NT_DEFINE_BOX(11) NT_DEFINE_BOX(12) NT_DEFINE_BOX(13) NT_DEFINE_BOX(14) NT_DEFINE_BOX(15) NT_DEFINE_BOX(16)
 #endif

@@ -9,6 +9,13 @@
     int nt_composite_fixed_##N(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg);
 NT_DECLARE_FIXED(3) NT_DECLARE_FIXED(4) NT_DECLARE_FIXED(5) NT_DECLARE_FIXED(6)
 NT_DECLARE_FIXED(7) NT_DECLARE_FIXED(8) NT_DECLARE_FIXED(9) NT_DECLARE_FIXED(10)
+// (BoxScene alone: 11..16)
+int nt_box_fixed_14(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_15(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_16(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_11(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_12(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_13(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 
 namespace {
 
@@ -1583,6 +1590,12 @@ int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &t
         case 8: nt_box_fixed_8(li, cam, tg); break;
         case 9: nt_box_fixed_9(li, cam, tg); break;
         case 10: nt_box_fixed_10(li, cam, tg); break;
+        case 11: nt_box_fixed_11(li, cam, tg); break;
+        case 12: nt_box_fixed_12(li, cam, tg); break;
+        case 13: nt_box_fixed_13(li, cam, tg); break;
+        case 14: nt_box_fixed_14(li, cam, tg); break;
+        case 15: nt_box_fixed_15(li, cam, tg); break;
+        case 16: nt_box_fixed_16(li, cam, tg); break;
         default: {
             // packed plain RGB of <= 10 bits in one aligned dword: the rows kernel (codes + lean loops), if its n-vectors fit LDS
             const size_t lds_rows = ((size_t)2 * li.n * 256 + (size_t)4 * li.n + 4) * sizeof(float);
