@@ -254,12 +254,12 @@ def main():
                      # tools/micro/store_rate.hip, recorded in profiles/README.md): the practical ceiling of this workload
                      "store_only": {"GBs": STORE_ONLY_GBS, "frac": round(achieved / STORE_ONLY_GBS, 4), "source": "tools/micro/store_rate.hip"},
                      "algorithmic_bytes_per_launch": float(own_rows) * W * fmt.bytes_per_pixel * F,
-                     "kernel": "box_tile_kernel<6, false, ROWS, WAVES> (64, 1 for the full frame) with box_redo_kernel<6, false, true, SPLIT> after it (one "
-                               "nt_render_frames_device call = these two + the camera upload kernel)",
+                     "kernel": "box_tile_kernel<6, false, ROWS, WAVES> (64, 1 for the full frame; one nt_render_frames_device call = this kernel + "
+                               "the camera upload kernel: up to eight dimensions it needs no box_redo_kernel after it)",
                      "avg_launch_us": round(kernel_us, 2),
                      "algorithmic_bytes_per_ray": fmt.bytes_per_pixel,
                      "note": "BoxScene reads no scene memory: the only algorithmic HBM traffic is the packed framebuffer "
-                             "(4 B/ray); the kernels are VALU- and scalar-issue bound (see DESIGN.md), so the HBM "
+                             "(4 B/ray); the kernel is bound by instruction issue and latency, not by HBM (see DESIGN.md 4.1), so the HBM "
                              "fraction is structurally small -- `valu` is the bound that binds; avg_launch_us spans the kernels of a call"},
         "delivery": {"what": "RCCL gather to rank 0" if world > 1 else "D2H copy to pinned host memory",
                      "ms_per_frame": round(gather_ms, 4), "verified_equal_to_single_gpu_frame": gather_ok,

@@ -748,8 +748,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             li.cull_buf = (uint32_t *)ds->cull.p;
             if (fused) {
                 if (int e = row_table(ds, tg, tg.rowtab)) return e;
-                if (int e = ds->ties.ensure((size_t)job.nframes * tg.row_count * ((tg.width + 63) / 64) * sizeof(uint32_t))) return e;
-                li.tie_buf = (uint32_t *)ds->ties.p;
+                li.tie_buf = nullptr;               // (round 2's end: the tie sets never leave the tile kernel)
             }
         }
         r = nt_launch_box(li, cam, tg);

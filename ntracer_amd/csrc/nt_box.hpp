@@ -109,6 +109,10 @@ __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir
 // here (~2^-22*(1 + |o_j|)): under 2e-6*(1 + max|o_j|) together, 5x below this.  (Rounds 1 and most of 2 ran with 3e-5; the
 // narrower band sends a third fewer stretches to box_redo_kernel.  Builds with -DNT_BOX_MARGIN=2e-6f, the bound itself, and
 // 5e-6f render the 440 full frames of tools/box_soak.py byte for byte like the oracle; at 5e-7f frames start to differ.)
+// box_tile_kernel renders everything itself -- no box_redo_kernel after it -- up to this dimension (packed RGB; fp32x3: always)
+#ifndef NT_BOX_INLINE_MAX_N
+#define NT_BOX_INLINE_MAX_N 8
+#endif
 #ifndef NT_BOX_MARGIN
 #define NT_BOX_MARGIN 1e-5f
 #endif
@@ -310,9 +314,9 @@ template <int N, bool PLAIN, bool DEFER = false, bool REDO = false, bool F32 = f
 __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr, const float (&org)[N], float (&dir)[N], float sq,
                                           const float (&dots)[4], float sx, float sy, float margin, bool rowhit = true, int face = -1,
                                           uint32_t sets = 0u, bool noclass = false) {
-    // noclass (wave-uniform; box_tile_kernel<F32 = true> only, which has no second kernel): a near-tie stretch (code 14) --
+    // noclass (wave-uniform; box_tile_kernel where it has no second kernel: F32, or N <= 8): a near-tie stretch (code 14) --
     // as in box_redo_kernel, no sorting into clear and unclear first
-    constexpr bool INL = F32 && !REDO && !DEFER;
+    constexpr bool INL = (F32 || PLAIN) && !REDO && !DEFER;
     const bool redo = REDO || (INL && noclass);
     // rowhit (wave-uniform): the culling bit of this 64-pixel stretch of the row, see box_cull_kernel
     // face (wave-uniform) >= 0: every ray of the stretch is known to hit that face (a one-face row of box_tile_kernel whose
@@ -988,7 +992,12 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     __shared__ unsigned long long s_rows[4];
     // F32: this kernel is bound by its stores (12 bytes a pixel), not by vector instructions, and renders the near-tie and
     // unclear stretches itself -- no second kernel; the tie sets of its rows stay in LDS
-    constexpr bool SETS_LDS = F32 && N <= 8;
+    // ... and so does the packed format up to eight dimensions, where the codes wave's tie sets (LDS) give the near-tie
+    // stretches their short cut: the second kernel's work costs this kernel a tenth of its time and saves a third of it
+    // (BoxScene(6): 423 -> 410 us a call; 75 VGPRs instead of 70).  Beyond eight -- no tie sets -- it loses: BoxScene(10) 4096^2
+    // 6-12 % slower without box_redo_kernel, BoxScene(16) 15 %.
+    constexpr bool ALLIN = F32 || N <= NT_BOX_INLINE_MAX_N;
+    constexpr bool SETS_LDS = ALLIN && N <= 8;
     __shared__ uint32_t s_sets[SETS_LDS ? 64 : 1];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -1028,7 +1037,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
                 const uint32_t sets = (uint32_t)(cs >> 32);
                 // (every marked stretch gets a fresh entry: the sets here, 0 from the wave that marks a row it looked at)
                 row_sets = sets;
-                if (!F32 && N <= 8 && code >= 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
+                if (!ALLIN && N <= 8 && code >= 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
             }
         }
         if (SETS_LDS) s_sets[lane] = row_sets;
@@ -1136,8 +1145,8 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
         const nt_rowtab tab = (nt_rowtab)tg.rowtab + (tg.row_begin + row0);
         // (bit rr <-> row row0 + rr; code 14 -- a near-tie stretch -- is not looked at here unless this kernel is all there is)
         uint32_t quick = (uint32_t)(rows_culled >> (16 * half)) & valid, inner = (uint32_t)(rows_face >> (16 * half)) & valid;
-        uint32_t todo = (uint32_t)((F32 ? rows_rays | rows_tie : rows_rays) >> (16 * half)) & valid;
-        if (!F32) redo_bits = (uint32_t)(rows_tie >> (16 * half)) & valid;
+        uint32_t todo = (uint32_t)((ALLIN ? rows_rays | rows_tie : rows_rays) >> (16 * half)) & valid;
+        if (!ALLIN) redo_bits = (uint32_t)(rows_tie >> (16 * half)) & valid;
         if (!F32) {
             // ---- packed RGB: guarded rsq quantisation (see box_kernel<N, true>)
             if (!fastsq) {
@@ -1304,19 +1313,19 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
             for (int j = 1; j < N; ++j) sq = sq + dir[j] * dir[j];
             // (a row with a face code is here because its cheap quantisation failed: the face is known)
             const int rcode = (int)((uint32_t)(rowcodes >> (4 * rr)) & 15u);
-            if (F32) {
+            if (ALLIN) {
                 // everything here: classification, the reference's arithmetic on the faces in question (on the stretch's tie sets
                 // for a near-tie stretch), box_color for rays that start on or in the cube
                 uint32_t sets = 0u;
                 if (SETS_LDS) sets = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sets[wv * R + 16 * half + rr]);
-                box_pixel<N, false, false, false, true>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit, rcode >= 1 && rcode <= 13 ? rcode - 1 : -1, sets,
-                                                         rcode == 14);
+                box_pixel<N, !F32, false, false, F32>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit, rcode >= 1 && rcode <= 13 ? rcode - 1 : -1, sets,
+                                                       rcode == 14);
             } else if (!box_pixel<N, true, true, false, false>(tg, pr, org, dir, sq, dots, sx, sy, margin, rowhit, rcode >= 1 && rcode <= 13 ? rcode - 1 : -1)) {
                 redo_bits |= 1u << rr;
             }
         }
         // mark the rows left over in the redo bitmap (clean on entry: box_redo_kernel zeroes what it has read)
-        if (!F32 && lane == 0) {
+        if (!ALLIN && lane == 0) {
             while (redo_bits != 0u) {
                 const int rr = __builtin_ctz(redo_bits);
                 redo_bits &= redo_bits - 1u;
@@ -1377,8 +1386,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         // the tie sets of the marked stretches, [frame][row][stretch] dwords (written with the mark)
         // (a buffer of their own: the bitmap's buffer must hold nothing but the bitmap, which has to be all zero whatever the
         // next launch's geometry is)
-        tg.tie_sets = N <= 8 ? li.tie_buf : nullptr;
-        if (const char *e = getenv("NTRACER_BOX_TIE_SETS")) { if (atoi(e) == 0) tg.tie_sets = nullptr; }        // (A/B)
+        tg.tie_sets = nullptr;               // (the tie sets stay in LDS: only kernels that need no second kernel have them)
         // few rows in flight: two waves per redo word
         const long long rwords = (long long)tg.row_count * li.nframes * tg.redo_words;
         int split = rwords < 48 * 1024 ? 2 : 1;                 // (87k words: one wave 3 % faster; 44k: even; 22k: two waves 2 % faster;
@@ -1391,8 +1399,10 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
             else if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, false, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
             else if (r16) hipLaunchKernelGGL((box_tile_kernel<N, false, 16, 4>), tgrid, dim3(256), 0, st, cf, tg);
             else hipLaunchKernelGGL((box_tile_kernel<N, false, 8, 4>), tgrid, dim3(256), 0, st, cf, tg);
-            if (split == 2) hipLaunchKernelGGL((box_redo_kernel<N, false, true, 2>), rgrid, dim3(256), 0, st, cf, tg);
-            else hipLaunchKernelGGL((box_redo_kernel<N, false, true, 1>), rgrid, dim3(256), 0, st, cf, tg);
+            if (N > NT_BOX_INLINE_MAX_N) {          // (up to there the tile kernel leaves nothing behind)
+                if (split == 2) hipLaunchKernelGGL((box_redo_kernel<N, false, true, 2>), rgrid, dim3(256), 0, st, cf, tg);
+                else hipLaunchKernelGGL((box_redo_kernel<N, false, true, 1>), rgrid, dim3(256), 0, st, cf, tg);
+            }
         } else {
             if (r64) hipLaunchKernelGGL((box_tile_kernel<N, true, 64, 1>), tgrid, dim3(64), 0, st, cf, tg);
             else if (r16 && wpb == 3) hipLaunchKernelGGL((box_tile_kernel<N, true, 16, 3>), tgrid, dim3(192), 0, st, cf, tg);
