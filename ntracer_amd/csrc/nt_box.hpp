@@ -113,6 +113,10 @@ __device__ __forceinline__ void box_color(const float (&o)[N], const float (&dir
 #ifndef NT_BOX_INLINE_MAX_N
 #define NT_BOX_INLINE_MAX_N 8
 #endif
+// ... which is as far as the codes wave works out tie sets (bits 0..9 and 10..19 of a dword: at most 10)
+#ifndef NT_BOX_SETS_MAX_N
+#define NT_BOX_SETS_MAX_N NT_BOX_INLINE_MAX_N
+#endif
 #ifndef NT_BOX_MARGIN
 #define NT_BOX_MARGIN 1e-5f
 #endif
@@ -997,7 +1001,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     // (BoxScene(6): 423 -> 410 us a call; 75 VGPRs instead of 70).  Beyond eight -- no tie sets -- it loses: BoxScene(10) 4096^2
     // 6-12 % slower without box_redo_kernel, BoxScene(16) 15 %.
     constexpr bool ALLIN = F32 || N <= NT_BOX_INLINE_MAX_N;
-    constexpr bool SETS_LDS = ALLIN && N <= 8;
+    constexpr bool SETS_LDS = ALLIN && N <= NT_BOX_SETS_MAX_N;
     __shared__ uint32_t s_sets[SETS_LDS ? 64 : 1];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -1032,7 +1036,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
             if (y < tg.height) {
                 // (N > 8: the sets' arithmetic would raise the kernel's register allocation -- 124 VGPRs and spills at N = 10 --
                 // for every row; those dimensions go without)
-                const unsigned long long cs = box_stretch_code2<N, (N <= 8)>(org, right, up, fwd, tg, y, (int)blockIdx.x);
+                const unsigned long long cs = box_stretch_code2<N, (N <= NT_BOX_SETS_MAX_N)>(org, right, up, fwd, tg, y, (int)blockIdx.x);
                 code = (uint32_t)cs;
                 const uint32_t sets = (uint32_t)(cs >> 32);
                 // (every marked stretch gets a fresh entry: the sets here, 0 from the wave that marks a row it looked at)
