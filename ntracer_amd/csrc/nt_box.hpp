@@ -1006,6 +1006,11 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef NT_EXP_TRACE
+    const unsigned long long trace_t0 = wall_clock64();          // ablation builds: per-wave residency record (tools/box_wave_trace.py)
+    unsigned trace_rows = 0u;                                    // rows by class: culled | one face << 8 | ray by ray << 16 | near-tie << 24
+    unsigned long long trace_t1 = 0ull;                          // end of the codes phase
+#endif
     float org[N], right[N], up[N], fwd[N], dir[N];
     load_camera<N>(cam, org, right, up, fwd);
     float margin = fabsf(org[0]);
@@ -1068,6 +1073,9 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
         }
     }
     __syncthreads();
+#ifdef NT_EXP_TRACE
+    trace_t1 = wall_clock64();
+#endif
     // Sixteen rows at a time (their codes fill a qword), once or -- R == 32 -- twice per wave: what depends on the column
     // alone (forward + right*sx, the quadratic for |dir|^2) is set up once for all the wave's rows.
     constexpr int HALVES = R >= 32 ? R / 16 : 1, RH = R / HALVES;
@@ -1151,6 +1159,11 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
         uint32_t quick = (uint32_t)(rows_culled >> (16 * half)) & valid, inner = (uint32_t)(rows_face >> (16 * half)) & valid;
         uint32_t todo = (uint32_t)((ALLIN ? rows_rays | rows_tie : rows_rays) >> (16 * half)) & valid;
         if (!ALLIN) redo_bits = (uint32_t)(rows_tie >> (16 * half)) & valid;
+#ifdef NT_EXP_TRACE
+        trace_rows += (unsigned)__builtin_popcount(quick) | ((unsigned)__builtin_popcount(inner) << 8) |
+                      ((unsigned)__builtin_popcount((uint32_t)(rows_rays >> (16 * half)) & valid) << 16) |
+                      ((unsigned)__builtin_popcount((uint32_t)(rows_tie >> (16 * half)) & valid) << 24);
+#endif
         if (!F32) {
             // ---- packed RGB: guarded rsq quantisation (see box_kernel<N, true>)
             if (!fastsq) {
@@ -1340,6 +1353,16 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
         }
         }           // (sixteen rows)
     }
+#ifdef NT_EXP_TRACE
+    if (lane == 0) {       // the records lie behind the last frame: [frame][tile row][column][wave] x 4 qwords
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(tg.dest + (long long)gridDim.z * tg.frame_stride) +
+                                 ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WAVES + wv) * 4;
+        tr[0] = trace_t0;
+        tr[1] = wall_clock64();
+        tr[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+        tr[3] = (unsigned long long)trace_rows | ((trace_t1 - trace_t0) << 32);
+    }
+#endif
 #undef NT_ROW_LOAD
 #undef NT_ROW_OFF
 #undef NT_ROW_PTR
