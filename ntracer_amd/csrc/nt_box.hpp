@@ -1011,15 +1011,29 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     unsigned trace_rows = 0u;                                    // rows by class: culled | one face << 8 | ray by ray << 16 | near-tie << 24
     unsigned long long trace_t1 = 0ull;                          // end of the codes phase
 #endif
+    // Work order.  Blocks start in grid order -- column, tile row, then z -- and a wave with sixty-four rows to sort ray by ray
+    // lives ten times as long as one with none: with z = frame the long waves of the last frames were still running, almost
+    // alone, 60 us after the grid had been handed out (tools/box_wave_trace.py).  The long waves are in the middle columns of
+    // the image (the scripts' cameras look at the cube), so those columns run tg.lead_frames frames ahead of the outer ones: z
+    // counts lead_frames + nframes slots, slot z holds the middle columns of frame z and the outer columns of frame
+    // z - lead_frames; the grid ends on short waves only.  (A block whose frame does not exist leaves at once.)
+    const unsigned nframes = gridDim.z - (unsigned)tg.lead_frames;
+    unsigned frame = blockIdx.z;
+    if (tg.lead_frames > 0) {
+        const unsigned cols = gridDim.x, q = cols / 4u;
+        const bool middle = blockIdx.x >= q && blockIdx.x < cols - q;
+        if (!middle) frame -= (unsigned)tg.lead_frames;          // (wraps for the first slots: >= nframes)
+        if (frame >= nframes) return;
+    }
     float org[N], right[N], up[N], fwd[N], dir[N];
-    load_camera<N>(cam, org, right, up, fwd);
+    load_camera<N>(cam, frame, org, right, up, fwd);
     float margin = fabsf(org[0]);
 #pragma unroll
     for (int j = 1; j < N; ++j) margin = fmaxf(margin, fabsf(org[j]));
     margin = NT_BOX_MARGIN * (1.0f + margin);
     float dots[4];
     if (cam.buf) {
-        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        const float *dp = cam.buf + (size_t)nframes * 4 * N + (size_t)frame * 4;
         dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
     } else {
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
@@ -1027,7 +1041,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     const int tile_row0 = (int)blockIdx.y * WAVES * R;
     // ---- phase 1: the tile's stretch codes, one row per lane of one wave -- a different one from block to block, so that
     // the extra work does not always land on the same SIMD of a CU
-    if (wv == (int)((blockIdx.x + blockIdx.y + blockIdx.z) % (unsigned)WAVES)) {
+    if (wv == (int)((blockIdx.x + blockIdx.y + frame) % (unsigned)WAVES)) {
         uint32_t code = 0u;
         uint32_t row_sets = 0u;
         const int trow = tile_row0 + lane;
@@ -1046,7 +1060,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
                 const uint32_t sets = (uint32_t)(cs >> 32);
                 // (every marked stretch gets a fresh entry: the sets here, 0 from the wave that marks a row it looked at)
                 row_sets = sets;
-                if (!ALLIN && N <= 8 && code >= 14u && tg.tie_sets) tg.tie_sets[((size_t)blockIdx.z * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
+                if (!ALLIN && N <= 8 && code >= 14u && tg.tie_sets) tg.tie_sets[((size_t)frame * tg.row_count + trow) * gridDim.x + blockIdx.x] = sets;
             }
         }
         if (SETS_LDS) s_sets[lane] = row_sets;
@@ -1083,14 +1097,14 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     if (wrow0 < tg.row_count) {
         typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(4))) const nt_u32x4 *nt_rowtab;
-        uint8_t *const frame_base = tg.dest + (long long)blockIdx.z * tg.frame_stride;
+        uint8_t *const frame_base = tg.dest + (long long)frame * tg.frame_stride;
         // What a row loop needs to know about its row -- sy of the ray source and the row's byte offset in a frame -- comes
         // from a table the host wrote (NtTarget::rowtab, 16 bytes per owned row: sy, -, offset), read through the scalar
         // data cache (constant address space: s_load_dwordx4): no vector instruction, nothing per lane
 #define NT_ROW_LOAD(rr)                     \
         const nt_u32x4 row_e = tab[(rr)];   \
         const float sy = __uint_as_float(row_e.x)
-#define NT_ROW_OFF() ((long long)(((unsigned long long)row_e.w << 32) | row_e.z) + (long long)blockIdx.z * tg.frame_stride)
+#define NT_ROW_OFF() ((long long)(((unsigned long long)row_e.w << 32) | row_e.z) + (long long)frame * tg.frame_stride)
         // a store goes to (row pointer: scalar registers) + (the lane's byte offset in the row: 32 bits) -- the addressing
         // mode of global_store with an SGPR base, no vector arithmetic on addresses
 #define NT_ROW_PTR() uniform_ptr(frame_base + (long long)(((unsigned long long)row_e.w << 32) | row_e.z))
@@ -1347,16 +1361,16 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
                 const int rr = __builtin_ctz(redo_bits);
                 redo_bits &= redo_bits - 1u;
                 if (N <= 8 && tg.tie_sets && ((uint32_t)(rowcodes >> (4 * rr)) & 15u) < 14u)
-                    tg.tie_sets[((size_t)blockIdx.z * tg.row_count + row0 + rr) * gridDim.x + blockIdx.x] = 0u;
-                atomicOr(tg.redo + ((size_t)blockIdx.z * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
+                    tg.tie_sets[((size_t)frame * tg.row_count + row0 + rr) * gridDim.x + blockIdx.x] = 0u;
+                atomicOr(tg.redo + ((size_t)frame * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
             }
         }
         }           // (sixteen rows)
     }
 #ifdef NT_EXP_TRACE
     if (lane == 0) {       // the records lie behind the last frame: [frame][tile row][column][wave] x 4 qwords
-        unsigned long long *tr = reinterpret_cast<unsigned long long *>(tg.dest + (long long)gridDim.z * tg.frame_stride) +
-                                 ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WAVES + wv) * 4;
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(tg.dest + (long long)nframes * tg.frame_stride) +
+                                 ((((size_t)frame * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WAVES + wv) * 4;
         tr[0] = trace_t0;
         tr[1] = wall_clock64();
         tr[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
@@ -1407,13 +1421,18 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         bool r64 = r16 && tg.row_count >= 512 && (long long)((tg.width + 63) / 64) * ((tg.row_count + 63) / 64) * li.nframes >= 32 * 1024;
         if (const char *e = getenv("NTRACER_BOX_R64")) r64 = r16 && atoi(e) != 0;        // (A/B)
         const int tile_rows = r64 ? 64 : wpb * (r16 ? 16 : 8);
-        const dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + tile_rows - 1) / tile_rows), (unsigned)li.nframes);
+        dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + tile_rows - 1) / tile_rows), (unsigned)li.nframes);
         tg.redo_words = ((tg.width + 63) / 64 + 31) / 32;
         tg.redo = li.cull_buf;                        // [frame][row][redo_words], all zero between launches
         // the tie sets of the marked stretches, [frame][row][stretch] dwords (written with the mark)
         // (a buffer of their own: the bitmap's buffer must hold nothing but the bitmap, which has to be all zero whatever the
         // next launch's geometry is)
         tg.tie_sets = nullptr;               // (the tie sets stay in LDS: only kernels that need no second kernel have them)
+        // the middle columns 48 frames ahead of the outer ones (32 .. 96 measure alike: -4 % on the 160-frame call, -3 % on a
+        // rank's eighth of it and on BoxScene(3); 16: -2 %), in launches of 16 frames or more
+        tg.lead_frames = li.nframes >= 16 ? (li.nframes < 48 ? li.nframes : 48) : 0;
+        if (const char *e = getenv("NTRACER_BOX_LEAD")) tg.lead_frames = atoi(e) > 0 && li.nframes > 1 ? atoi(e) : 0;        // (A/B)
+        tgrid.z += (unsigned)tg.lead_frames;
         // few rows in flight: two waves per redo word
         const long long rwords = (long long)tg.row_count * li.nframes * tg.redo_words;
         int split = rwords < 48 * 1024 ? 2 : 1;                 // (87k words: one wave 3 % faster; 44k: even; 22k: two waves 2 % faster;

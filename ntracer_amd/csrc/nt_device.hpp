@@ -70,6 +70,8 @@ struct NtTarget {
     // BoxScene tile kernel: per owned row (index = owned-row number; 64 entries of padding) 16 bytes {float sy = fovI*(y -
     // half_h); uint32 y < height; int64 byte offset of the row within a frame}, read with scalar loads; or nullptr
     const void *rowtab;
+    // box_tile_kernel: the middle columns of the image are started `lead_frames` frames ahead of the outer ones (see the kernel); 0: off
+    int lead_frames;
 };
 
 // Camera rows used by the ray source (camera.hpp:40-45): origin, right, up, forward.

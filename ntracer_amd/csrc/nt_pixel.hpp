@@ -301,9 +301,9 @@ __device__ __forceinline__ void emit_plain(const NtTarget &tg, const PixelRef &p
 // BoxScene, compile-time N (fixed_geometry.hpp -> registers)
 // --------------------------------------------------------------------------------------
 template <int N>
-__device__ __forceinline__ void load_camera(const NtCameraFixed &cam, float (&org)[N], float (&right)[N], float (&up)[N], float (&fwd)[N]) {
+__device__ __forceinline__ void load_camera(const NtCameraFixed &cam, unsigned frame, float (&org)[N], float (&right)[N], float (&up)[N], float (&fwd)[N]) {
     if (cam.buf) {
-        const float *c = cam.buf + (size_t)blockIdx.z * 4 * N;
+        const float *c = cam.buf + (size_t)frame * 4 * N;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             org[j] = c[j];
@@ -320,6 +320,10 @@ __device__ __forceinline__ void load_camera(const NtCameraFixed &cam, float (&or
             fwd[j] = cam.inl[3 * N + j];
         }
     }
+}
+template <int N>
+__device__ __forceinline__ void load_camera(const NtCameraFixed &cam, float (&org)[N], float (&right)[N], float (&up)[N], float (&fwd)[N]) {
+    load_camera<N>(cam, blockIdx.z, org, right, up, fwd);          // the frame is the grid's z almost everywhere
 }
 
 // flat_origin_ray_source::operator() (tracer.hpp:71-75)
