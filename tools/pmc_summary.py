@@ -19,9 +19,14 @@ def short(name):
     return re.sub(r"\(.*", "", name).strip()
 
 
+def newest(files):
+    """the newest file only: raw directories merged back from several GPU runs hold one set of files per run"""
+    return sorted(files, key=os.path.getmtime)[-1:]
+
+
 def collect(d):
     """{kernel: {counter: [per-dispatch sums]}}: a dispatch's counter value is the sum of its rows"""
-    files = glob.glob(os.path.join(raw, d, "*", "*counter_collection.csv"))
+    files = newest(glob.glob(os.path.join(raw, d, "*", "*counter_collection.csv")))
     per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -105,7 +110,7 @@ if c4:
 # kernel durations of the traced runs, per (kernel, grid): the bench mixes full-frame, one-eighth-band and fp32 calls
 for d, name in (("kt", "bench"), ("b8", "band8")):
     rows = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(raw, d, "*", "*_kernel_trace.csv")):
+    for f in newest(glob.glob(os.path.join(raw, d, "*", "*_kernel_trace.csv"))):
         for r in csv.DictReader(open(f)):
             rows[(short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))].append(
                 (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
@@ -113,7 +118,7 @@ for d, name in (("kt", "bench"), ("b8", "band8")):
         fh.write("kernel,grid_x,grid_y,grid_z,calls,avg_us,min_us,max_us\n")
         for (k, gx, gy, gz), v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
             fh.write('"%s",%s,%s,%s,%d,%.2f,%.2f,%.2f\n' % (k, gx, gy, gz, len(v), sum(v) / len(v), min(v), max(v)))
-            if name == "bench" and k.startswith("box_") and "<6, false" in k and gz == "160" and len(v) >= 40:
+            if name == "bench" and k.startswith("box_") and "<6, false" in k and gz.isdigit() and int(gz) >= 160 and len(v) >= 40:     # (160 frames + the lead slots)
                 # (the full-frame calls of the timed loop: the largest grid of that kernel)
                 cur = summary.setdefault("headline_kernel_us", {})
                 cur[k] = max(cur.get(k, 0.0), round(sum(v) / len(v), 2))
