@@ -1432,6 +1432,7 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         // rank's eighth of it and on BoxScene(3); 16: -2 %), in launches of 16 frames or more
         tg.lead_frames = li.nframes >= 16 ? (li.nframes < 48 ? li.nframes : 48) : 0;
         if (const char *e = getenv("NTRACER_BOX_LEAD")) tg.lead_frames = atoi(e) > 0 && li.nframes > 1 ? atoi(e) : 0;        // (A/B)
+        if ((long long)li.nframes + tg.lead_frames > 65535) tg.lead_frames = 0;        // (grid z)
         tgrid.z += (unsigned)tg.lead_frames;
         // few rows in flight: two waves per redo word
         const long long rwords = (long long)tg.row_count * li.nframes * tg.redo_words;
