@@ -1429,9 +1429,9 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         // next launch's geometry is)
         tg.tie_sets = nullptr;               // (the tie sets stay in LDS: only kernels that need no second kernel have them)
         // the middle columns 96 frames ahead of the outer ones (32 .. 96 measure alike on the 160-frame call: -4 %, and on
-        // BoxScene(3): -3 %; a rank's eighth of the call: -3 % with 48, -6 % with 96; 16: half of it), in launches of 16 frames
-        // or more
-        tg.lead_frames = li.nframes >= 16 ? (li.nframes < 96 ? li.nframes : 96) : 0;
+        // BoxScene(3): -3 %; a rank's eighth of the call: -3 % with 48, -6 % with 96; 16: half of it), in launches of 8 frames
+        // or more (eight 4096 x 4096 frames of BoxScene(10): 621 -> 693 Grays/s; four: no difference)
+        tg.lead_frames = li.nframes >= 8 ? (li.nframes < 96 ? li.nframes : 96) : 0;
         if (const char *e = getenv("NTRACER_BOX_LEAD")) tg.lead_frames = atoi(e) > 0 && li.nframes > 1 ? atoi(e) : 0;        // (A/B)
         if ((long long)li.nframes + tg.lead_frames > 65535) tg.lead_frames = 0;        // (grid z)
         tgrid.z += (unsigned)tg.lead_frames;
