@@ -69,9 +69,11 @@ struct ChanTable {
     NtChanDev *dev = nullptr;
 };
 
-// NtTarget::rowtab: what the BoxScene tile kernel needs to know about a row, per owned row of one (view, band split, pitch)
+// NtTarget::rowtab: what the BoxScene tile kernel needs to know about a row, per owned row of one (view, band split, pitch) --
+// or, with interleaved rows (NtTarget::row_il), per slot of one launch geometry
 struct RowTable {
     int height = 0, pitch = 0, rank = 0, world = 1, rows = 0, compact = 0;
+    int il = 0, il_rows = 0, il_count = 0;   // interleave stride (waves per column strip), rows a wave, rows of the launch
     uint32_t half_h = 0, fovI = 0;       // float bits
     void *dev = nullptr;
 };
@@ -371,14 +373,17 @@ int chan_table(DeviceState *ds, const Format &f, const NtChanDev *&dev_ptr) {
 // The row table of a launch geometry (cached: a render loop keeps its view, band split and pitch).  Entry i belongs to owned
 // row i: sy exactly as the ray source computes it (tracer.hpp:72-74: fovI * (y - half_h), two fp32 operations), whether
 // the row exists, and where it starts in a frame; 64 entries of padding, as a wave reads its sixteen rows unclamped.
-int row_table(DeviceState *ds, const NtTarget &tg, const void *&dev_ptr) {
+// Interleaved rows (tg.row_il = W > 0, il_rows = rows a wave): entry w * il_rows + rr belongs to row w + W * rr of the launch.
+int row_table(DeviceState *ds, const NtTarget &tg, int il_rows, const void *&dev_ptr) {
     uint32_t hh, fi;
     std::memcpy(&hh, &tg.half_h, 4);
     std::memcpy(&fi, &tg.fovI, 4);
     const int world = std::max(tg.band_world, 1);
+    const int il = tg.row_il;
     for (auto &t : ds->row_tables) {
         if (t->height == tg.height && t->pitch == tg.pitch && t->rank == tg.band_rank && t->world == world && t->rows == tg.band_rows &&
-            t->compact == tg.compact && t->half_h == hh && t->fovI == fi) {
+            t->compact == tg.compact && t->half_h == hh && t->fovI == fi && t->il == il &&
+            (il == 0 || (t->il_rows == il_rows && t->il_count == tg.row_count))) {
             dev_ptr = t->dev;
             return NT_OK;
         }
@@ -387,15 +392,29 @@ int row_table(DeviceState *ds, const NtTarget &tg, const void *&dev_ptr) {
     static_assert(sizeof(Entry) == 16, "16-byte row entries");
     std::vector<Entry> host;
     const int rows = std::max(tg.band_rows, 1);
-    for (int orow = 0;; ++orow) {
+    auto entry_of = [&](int orow, Entry &e) {            // false: no such band
         const int band = orow / rows;
         const int y = world > 1 ? (band * world + tg.band_rank) * rows + (orow - band * rows) : orow;
-        if ((world > 1 ? (band * world + tg.band_rank) * rows : orow) >= tg.height) break;
-        Entry e;
+        if ((world > 1 ? (band * world + tg.band_rank) * rows : orow) >= tg.height) return false;
         e.sy = tg.fovI * ((float)y - tg.half_h);
         e.valid = y < tg.height ? 1u : 0u;
         e.off = (long long)(tg.compact ? orow : y) * tg.pitch;
-        host.push_back(e);
+        return true;
+    };
+    if (il > 0) {
+        for (int w = 0; w < il; ++w)
+            for (int rr = 0; rr < il_rows; ++rr) {
+                Entry e{0.0f, 0u, 0};
+                const int row = w + il * rr;
+                if (row >= tg.row_count || !entry_of(tg.row_begin + row, e)) e = Entry{0.0f, 0u, 0};
+                host.push_back(e);
+            }
+    } else {
+        for (int orow = 0;; ++orow) {
+            Entry e;
+            if (!entry_of(orow, e)) break;
+            host.push_back(e);
+        }
     }
     for (int k = 0; k < 64; ++k) host.push_back(Entry{0.0f, 0u, 0});
     if (ds->row_tables.size() >= 8) {                       // a handful of geometries at a time
@@ -406,6 +425,7 @@ int row_table(DeviceState *ds, const NtTarget &tg, const void *&dev_ptr) {
     auto t = std::make_unique<RowTable>();
     t->height = tg.height; t->pitch = tg.pitch; t->rank = tg.band_rank; t->world = world; t->rows = tg.band_rows; t->compact = tg.compact;
     t->half_h = hh; t->fovI = fi;
+    t->il = il; t->il_rows = il_rows; t->il_count = tg.row_count;
     HIP_TRY(hipMalloc(&t->dev, host.size() * sizeof(Entry)));
     HIP_TRY(hipMemcpy(t->dev, host.data(), host.size() * sizeof(Entry), hipMemcpyHostToDevice));
     dev_ptr = t->dev;
@@ -747,7 +767,15 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
             li.cull_clean = fused ? 1 : 0;
             li.cull_buf = (uint32_t *)ds->cull.p;
             if (fused) {
-                if (int e = row_table(ds, tg, tg.rowtab)) return e;
+                // interleaved rows (the default for launches that start at their first owned row; NTRACER_BOX_INTERLEAVE=0: A/B):
+                // the waves of a column strip deal the rows out among themselves, so that the rows that need ray-by-ray work --
+                // which come in runs of dozens -- are spread over all of them instead of making a few waves ten times as long as
+                // the rest
+                const NtBoxTileGeom geom = nt_box_tile_geom(tg.width, tg.row_count, job.nframes);
+                const char *eil = getenv("NTRACER_BOX_INTERLEAVE");
+                const int tile_rows = geom.rows * geom.waves;
+                tg.row_il = (tg.row_begin == 0 && !(eil && atoi(eil) == 0)) ? (tg.row_count + tile_rows - 1) / tile_rows * geom.waves : 0;
+                if (int e = row_table(ds, tg, geom.rows, tg.rowtab)) return e;
                 li.tie_buf = nullptr;               // (round 2's end: the tie sets never leave the tile kernel)
             }
         }

@@ -1044,7 +1044,8 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     if (wv == (int)((blockIdx.x + blockIdx.y + frame) % (unsigned)WAVES)) {
         uint32_t code = 0u;
         uint32_t row_sets = 0u;
-        const int trow = tile_row0 + lane;
+        // lane <-> slot tile_row0 + lane = row rr of wave w; interleaved: that wave's rr-th row is w + W * rr (NtTarget::row_il)
+        const int trow = tg.row_il > 0 ? ((int)blockIdx.y * WAVES + lane / R) + tg.row_il * (lane % R) : tile_row0 + lane;
         if (lane < WAVES * R && trow < tg.row_count) {
             const int orow = tg.row_begin + trow;
             int y = orow;
@@ -1093,8 +1094,10 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     // Sixteen rows at a time (their codes fill a qword), once or -- R == 32 -- twice per wave: what depends on the column
     // alone (forward + right*sx, the quadratic for |dir|^2) is set up once for all the wave's rows.
     constexpr int HALVES = R >= 32 ? R / 16 : 1, RH = R / HALVES;
-    const int wrow0 = tile_row0 + wv * R;
-    if (wrow0 < tg.row_count) {
+    const int wrow0 = tile_row0 + wv * R;                     // the wave's first slot (its first row when rows are not interleaved)
+    const int il = tg.row_il;                                 // (scalar) 0, or the stride between a wave's rows
+    const int wfirst = il > 0 ? (int)blockIdx.y * WAVES + wv : wrow0;
+    if (wfirst < tg.row_count) {
         typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(4))) const nt_u32x4 *nt_rowtab;
         uint8_t *const frame_base = tg.dest + (long long)frame * tg.frame_stride;
@@ -1153,22 +1156,25 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
         const unsigned long long rows_culled = rows_of(0), rows_face = rows_of(1), rows_rays = rows_of(2), rows_tie = rows_of(3);
 #pragma unroll 1
         for (int half = 0; half < HALVES; ++half) {
-        const int row0 = wrow0 + 16 * half;
-        if (row0 >= tg.row_count) break;
+        const int row0 = wrow0 + 16 * half;                   // slot of the half's first row
+        const int hfirst = il > 0 ? wfirst + il * 16 * half : row0;        // ... and that row
+        if (hfirst >= tg.row_count) break;
         uint32_t redo_bits = 0u;                              // rows (bit rr) left to box_redo_kernel
         const int cw = (R >= 32 ? (R / 8) * wv + 2 * half : 2 * wv);
         unsigned long long rowcodes = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[cw + 1]) << 32) |
                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)s_code[cw]);
         // Which of these rows exist: one row per lane (lane l <-> row row0 + l).  Every lane stays active in the row
         // loops -- lanes past the right edge redo the last pixel (same bytes, same value) instead of leaving
-        const int lorow = tg.row_begin + row0 + lane;
+        const int lrow = il > 0 ? hfirst + il * lane : row0 + lane;
+        const int lorow = tg.row_begin + lrow;
         int ly = lorow;
         if (tg.band_world > 1) {
             const int band = lorow / tg.band_rows;
             ly = (band * tg.band_world + tg.band_rank) * tg.band_rows + (lorow - band * tg.band_rows);
         }
-        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < RH && row0 + lane < tg.row_count && ly < tg.height);
-        const nt_rowtab tab = (nt_rowtab)tg.rowtab + (tg.row_begin + row0);
+        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(lane < RH && lrow < tg.row_count && ly < tg.height);
+        // (interleaved rows: the table is in slot order and belongs to this launch's row range)
+        const nt_rowtab tab = (nt_rowtab)tg.rowtab + (il > 0 ? row0 : tg.row_begin + row0);
         // (bit rr <-> row row0 + rr; code 14 -- a near-tie stretch -- is not looked at here unless this kernel is all there is)
         uint32_t quick = (uint32_t)(rows_culled >> (16 * half)) & valid, inner = (uint32_t)(rows_face >> (16 * half)) & valid;
         uint32_t todo = (uint32_t)((ALLIN ? rows_rays | rows_tie : rows_rays) >> (16 * half)) & valid;
@@ -1360,9 +1366,10 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
             while (redo_bits != 0u) {
                 const int rr = __builtin_ctz(redo_bits);
                 redo_bits &= redo_bits - 1u;
+                const int mrow = il > 0 ? hfirst + il * rr : row0 + rr;
                 if (N <= 8 && tg.tie_sets && ((uint32_t)(rowcodes >> (4 * rr)) & 15u) < 14u)
-                    tg.tie_sets[((size_t)frame * tg.row_count + row0 + rr) * gridDim.x + blockIdx.x] = 0u;
-                atomicOr(tg.redo + ((size_t)frame * tg.row_count + row0 + rr) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
+                    tg.tie_sets[((size_t)frame * tg.row_count + mrow) * gridDim.x + blockIdx.x] = 0u;
+                atomicOr(tg.redo + ((size_t)frame * tg.row_count + mrow) * tg.redo_words + (blockIdx.x >> 5), 1u << (blockIdx.x & 31));
             }
         }
         }           // (sixteen rows)
@@ -1404,23 +1411,16 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
     const bool fmt_f32 = tg.plain_f32[0] >= 0 && tg.bpp == 12 && tg.aligned4;
     if (li.cull_buf && tg.rowtab && !tg.colors_out && BoxRows<N>::value > 1 && (fmt_rgb || fmt_f32) && li.box_path != 0 && li.cull_clean) {
         hipStream_t st = (hipStream_t)li.stream;
-        // sixteen rows a lane once there are waves to spare (the per-wave set-up is a fifth of the work at eight) -- unless
-        // tiles of 64 rows would hang much further over the bottom of the launch than tiles of 32
-        const long long waves8 = (long long)((tg.width + 63) / 64) * ((tg.row_count + 31) / 32) * li.nframes * 4;
-        const bool r16 = waves8 >= 64 * 1024;
-        // waves per block (large launches): the count that leaves the fewest idle waves below the last row
-        int wpb = 4;
-        if (r16) {
-            const int groups = (tg.row_count + 15) / 16;                   // waves with rows, per column
-            if ((groups + 2) / 3 * 3 < (groups + 3) / 4 * 4) wpb = 3;
-        }
-        // sixty-four rows a lane, one wave a block (tiles of 64 rows as with 4 x 16: the wave works out its own codes, and the
-        // set-up per column is shared by four times the rows) once the launch is tall enough for such tiles to fit it well
-        // and has waves enough even so (four 4096 x 4096 frames are 16 384 such waves: 7 % slower than with 16 rows a wave;
-        // sixteen frames: 9 % faster)
-        bool r64 = r16 && tg.row_count >= 512 && (long long)((tg.width + 63) / 64) * ((tg.row_count + 63) / 64) * li.nframes >= 32 * 1024;
-        if (const char *e = getenv("NTRACER_BOX_R64")) r64 = r16 && atoi(e) != 0;        // (A/B)
-        const int tile_rows = r64 ? 64 : wpb * (r16 ? 16 : 8);
+        // rows a wave x waves a block (nt_box_tile_geom, nt_device.hpp -- the host's row table follows the same decision):
+        // sixteen rows a lane once there are waves to spare (the per-wave set-up is a fifth of the work at eight), three waves a
+        // block instead of four when that leaves fewer idle waves below the last row; sixty-four rows a lane, one wave a block
+        // (the wave works out its own codes, and the set-up per column is shared by four times the rows) once the launch is tall
+        // enough for such tiles to fit it well and has waves enough even so (four 4096 x 4096 frames are 16 384 such waves: 7 %
+        // slower than with 16 rows a wave; sixteen frames: 9 % faster)
+        const NtBoxTileGeom geom = nt_box_tile_geom(tg.width, tg.row_count, li.nframes);
+        const bool r64 = geom.rows == 64, r16 = geom.rows == 16;
+        const int wpb = geom.waves;
+        const int tile_rows = geom.rows * geom.waves;
         dim3 tgrid((unsigned)((tg.width + 63) / 64), (unsigned)((tg.row_count + tile_rows - 1) / tile_rows), (unsigned)li.nframes);
         tg.redo_words = ((tg.width + 63) / 64 + 31) / 32;
         tg.redo = li.cull_buf;                        // [frame][row][redo_words], all zero between launches

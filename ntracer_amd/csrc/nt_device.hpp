@@ -2,6 +2,7 @@
 // (nt_box.hpp, nt_composite.hpp, nt_var.hip).  gfx950 only.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #define NT_DEV_MAX_DIM 64
 #define NT_DEV_MAX_FIXED 10
@@ -70,6 +71,11 @@ struct NtTarget {
     // BoxScene tile kernel: per owned row (index = owned-row number; 64 entries of padding) 16 bytes {float sy = fovI*(y -
     // half_h); uint32 y < height; int64 byte offset of the row within a frame}, read with scalar loads; or nullptr
     const void *rowtab;
+    // box_tile_kernel, interleaved rows: 0 = a wave renders ROWS consecutive rows (table entry = owned-row number); W > 0 = the
+    // W waves of a column strip (W = gridDim.y * WAVES) deal the rows out among themselves, wave w renders rows w, w + W,
+    // w + 2W, ... -- every wave of a strip then holds the same share of the rows that need ray-by-ray work -- and the row
+    // table is in SLOT order: entry w * ROWS + rr belongs to row w + W * rr (valid = 0 past the last row).
+    int row_il;
     // box_tile_kernel: the middle columns of the image are started `lead_frames` frames ahead of the outer ones (see the kernel); 0: off
     int lead_frames;
 };
@@ -165,6 +171,27 @@ struct NtLaunchInfo {
     uint32_t *tie_buf;        // BoxScene: scratch for the tie sets of the fused path, nframes * row_count * ceil(width/64) dwords (or nullptr)
     uint32_t *cull_buf;       // BoxScene: scratch for the row culling bits, 5 * nframes * row_count * ceil(ceil(width/64)/32) dwords: stretch codes, then redo bits (or nullptr)
 };
+
+// box_tile_kernel's block shape for a launch, decided in one place because the host's row table (nt_api.cpp) follows it:
+// 64 rows a wave and one wave a block for tall launches with waves to spare; otherwise 16 rows a wave (8 in small launches),
+// four waves a block, or three when that leaves fewer idle waves below the last row (see launch_box_fixed).
+struct NtBoxTileGeom { int rows, waves; };
+static inline NtBoxTileGeom nt_box_tile_geom(int width, int row_count, int nframes) {
+    const long long cols = (width + 63) / 64;
+    const long long waves8 = cols * ((row_count + 31) / 32) * nframes * 4;
+    const bool r16 = waves8 >= 64 * 1024;
+    int wpb = 4;
+    if (r16) {
+        const int groups = (row_count + 15) / 16;                   // waves with rows, per column
+        if ((groups + 2) / 3 * 3 < (groups + 3) / 4 * 4) wpb = 3;
+    }
+    bool r64 = r16 && row_count >= 512 && cols * ((row_count + 63) / 64) * nframes >= 32 * 1024;
+    if (const char *e = getenv("NTRACER_BOX_R64")) r64 = r16 && atoi(e) != 0;        // (A/B)
+    NtBoxTileGeom g;
+    g.rows = r64 ? 64 : (r16 ? 16 : 8);
+    g.waves = r64 ? 1 : wpb;
+    return g;
+}
 
 int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 int nt_launch_composite(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg);
