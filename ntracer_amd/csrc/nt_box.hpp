@@ -1432,6 +1432,10 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         // BoxScene(3): -3 %; a rank's eighth of the call: -3 % with 48, -6 % with 96; 16: half of it), in launches of 8 frames
         // or more (eight 4096 x 4096 frames of BoxScene(10): 621 -> 693 Grays/s; four: no difference)
         tg.lead_frames = li.nframes >= 8 ? (li.nframes < 96 ? li.nframes : 96) : 0;
+        // ... with interleaved rows (round 3) a strip's waves are all alike and little is left for the lead to do: 160-frame call
+        // 358 us without, 347 with 32, 354 with 96; 32- / 64- / 320-frame calls 1-2 % better with 8..16 than without and than
+        // with more; sixteen 4096 x 4096 frames of BoxScene(10) 3 % WORSE with 16 than without (tools/il_ab.py --var NTRACER_BOX_LEAD)
+        if (tg.row_il > 0) tg.lead_frames = li.nframes >= 32 ? 16 : 0;
         if (const char *e = getenv("NTRACER_BOX_LEAD")) tg.lead_frames = atoi(e) > 0 && li.nframes > 1 ? atoi(e) : 0;        // (A/B)
         if ((long long)li.nframes + tg.lead_frames > 65535) tg.lead_frames = 0;        // (grid z)
         tgrid.z += (unsigned)tg.lead_frames;
