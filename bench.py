@@ -93,20 +93,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="only the timed headline loop (the target of the rocprofv3 --pmc passes)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the N-rank plumbing (launcher, band split, barriers, gather over gloo): "
+                    "no GPU, no kernels, no throughput -- used by tests/test_bench_launch.py")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        # a bare `python3 bench.py --gpus N`: start the N ranks ourselves -- fresh child processes, before this one has
+        # loaded the library or touched the GPU -- and leave with their status; rank 0's JSON line goes straight to our stdout
+        sys.exit(self_launch(args.gpus))
+    if world != max(args.gpus, 1):
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, world, rank)
 
     import torch
     import ntracer_amd
     from ntracer_amd import _lib, tracern
     from ntracer_amd import distributed as ntd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                     % (args.gpus, args.gpus, args.gpus))
     # rehearsal hooks (used only to exercise the N>1 code path on a 1-GPU box): several ranks on one device
     # cannot use RCCL, so NTRACER_BENCH_BACKEND=gloo NTRACER_BENCH_DEVICE=0 runs the same code over gloo
     backend = os.environ.get("NTRACER_BENCH_BACKEND", "nccl")
@@ -136,8 +143,7 @@ def main():
     opts.band_world = world
     opts.compact = 1
     opts.strict_reference = 0
-    # band height: the largest of 32 / 16 / 8 rows that leaves the busiest rank the fewest rows
-    band_rows = min((32, 16, 8), key=lambda b: (max(len(ntd.owned_rows(H, r, world, b)) for r in range(world)), -b))
+    band_rows = pick_band_rows(ntd, H, world)
     opts.band_rows = band_rows
     own_rows = len(ntd.owned_rows(H, rank, world, band_rows))
     frame_bytes = own_rows * fmt.pitch
@@ -220,6 +226,14 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) / 5 * 1e3
 
+    # ---- BASELINE.json configs[4], the config north_star assigns to the 8-GPU split: BoxScene(10) 4096 x 4096, tiled over the
+    # ranks in row bands, RCCL gather verified (every rank takes part; reported next to the headline at every N)
+    cfg5 = None
+    if not args.headline_only:
+        try:
+            cfg5 = config5(torch, dist, ntracer_amd, tracern, _lib, ntd, rank, world, local_rank)
+        except Exception as e:           # never hide the headline
+            cfg5 = {"error": repr(e)[:300]}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -266,6 +280,8 @@ def main():
                      "value_incl_delivery": round(float(W) * H * F / ((ms_per_step + gather_ms * F) * 1e-3) / 1e6, 1)},
     }
 
+    if cfg5 is not None:
+        out["config5"] = cfg5
     if args.headline_only:
         args.no_cpu_baseline = args.no_extra = True
     if world == 1 and not args.headline_only:
@@ -274,7 +290,13 @@ def main():
             out["scaling_proxy"] = scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_per_step)
         except Exception as e:       # never hide the headline
             out["scaling_proxy"] = {"error": repr(e)}
-    if not args.no_cpu_baseline and world == 1:
+    if world == 1 and not args.headline_only:
+        try:
+            out["dropin_render"] = dropin_render(torch, ntracer_amd, tracern)
+        except Exception as e:
+            out["dropin_render"] = {"error": repr(e)[:300]}
+    if not args.no_cpu_baseline:
+        # (rank 0 only, after every timed region; at N > 1 the other ranks have left by now)
         out["cpu_baseline"] = cpu_baseline(origins, axes, W, H)
     if not args.no_extra and world == 1:
         try:
@@ -284,6 +306,70 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(gpus):
+    """One process per GPU through torch.distributed.run (the launcher the driver uses), rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """The N-rank plumbing without a GPU: rendezvous (gloo), the band split bench.py uses, barrier-bracketed timing with the MAX
+    over ranks, the gather of every rank's compact band buffer to rank 0 and its check against the whole frame.  The band
+    buffers hold a synthetic pattern (a function of row and byte position), not rendered pixels: nothing here stands in for
+    the HIP path, and the line says so (`dry_run`, value null)."""
+    import torch
+    import torch.distributed as dist
+    import ntracer_amd
+    from ntracer_amd import distributed as ntd
+    W, H = 1920, 1080
+    fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(*c) for c in RGBX8])
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    band_rows = pick_band_rows(ntd, H, world)
+    rows = ntd.owned_rows(H, rank, world, band_rows)
+
+    def pattern(ys):
+        y = torch.as_tensor(np.asarray(ys), dtype=torch.int64).reshape(-1, 1)
+        x = torch.arange(fmt.pitch, dtype=torch.int64).reshape(1, -1)
+        return ((y * 131 + x * 7 + (y * x) % 251) % 256).to(torch.uint8)
+
+    compact = pattern(rows)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.barrier()
+    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    full = ntd.gather_framebuffer(compact, fmt, rank, world, dst=0, band_rows=band_rows) if world > 1 else compact
+    if rank == 0:
+        ok = bool(torch.equal(full, pattern(range(H))))
+        print(json.dumps({"metric": "Mrays/s (primary+shadow), 6-D hypercube @1920x1080", "value": None, "unit": "Mrays/s", "dry_run": True,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "band_rows": band_rows,
+                          "rows_per_rank": [int(len(ntd.owned_rows(H, r, world, band_rows))) for r in range(world)],
+                          "gather_verified": ok, "barrier_loop_s": round(float(wall.item()), 4)}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def pick_band_rows(ntd, H, world):
+    """band height: the largest of 32 / 16 / 8 rows that leaves the busiest rank the fewest rows"""
+    return min((32, 16, 8), key=lambda b: (max(len(ntd.owned_rows(H, r, world, b)) for r in range(world)), -b))
 
 
 def _time_frames(torch, _lib, scene, fmt, origins, axes, frames, reps, opts=None, rows=None):
@@ -336,6 +422,136 @@ def scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_f
     return {"what": "rank 0 of 8: bands of 8 rows, %d of 1080 rows of each of the %d frames, on one GPU" % (rows, F),
             "ms_per_step": round(ms, 5), "full_step_ms": round(ms_full, 5), "implied_speedup_at_8": round(ms_full / ms, 2),
             "ideal_ms": round(ms_full / 8, 5), "measured_on": "1 GPU (no 8-GPU node was available to the builder)"}
+
+
+def config5(torch, dist, ntracer_amd, tracern, _lib, ntd, rank, world, local_rank, frames=16, steps=8, warmup=2):
+    """BASELINE.json configs[4]: BoxScene(10) (the reference sends n = 10 through its generic var_geometry module; here a
+    compile-time-N kernel), 4096 x 4096 RGBX8, `frames` cameras of the rotation per call, every frame tiled over the ranks in
+    row bands (band b -> rank b % N, as the headline), barrier-bracketed, MAX over ranks; then one frame gathered to rank 0
+    (RCCL) and compared with the same frame rendered whole."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "box_n10_4096x4096.npz"))
+    n, W, H = 10, 4096, 4096
+    sel = (np.arange(frames) * (len(g["origins"]) // frames)) % len(g["origins"])            # spread over the rotation
+    o = np.ascontiguousarray(g["origins"][sel], np.float32)
+    a = np.ascontiguousarray(g["axes"][sel], np.float32)
+    fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(*c) for c in RGBX8])
+    fst = fmt._as_struct()
+    band_rows = pick_band_rows(ntd, H, world)
+    opts = _lib.NtRenderOpts()
+    opts.device = local_rank
+    opts.band_rank, opts.band_world, opts.band_rows, opts.compact = rank, world, band_rows, 1
+    own = len(ntd.owned_rows(H, rank, world, band_rows))
+    fb = torch.empty((frames, own * fmt.pitch), dtype=torch.uint8, device="cuda")
+    sc = tracern.BoxScene(n)
+    st = torch.cuda.current_stream()
+    L = _lib.lib()
+
+    def go():
+        _lib.check(L.nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), own * fmt.pitch, frames, o.ctypes.data_as(_lib.f32p),
+                                             a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts), C.c_void_p(st.cuda_stream)))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        go()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        go()
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    wall = float(el.item())
+    ok = None
+    gather_ms = None
+    if dist is not None:
+        t1 = time.perf_counter()
+        full = ntd.gather_framebuffer(fb[frames - 1], fmt, rank, world, dst=0, band_rows=band_rows)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        if rank == 0:
+            whole = torch.empty(H * fmt.pitch, dtype=torch.uint8, device="cuda")
+            _lib.check(L.nt_render_frames_device(sc._handle, C.c_void_p(whole.data_ptr()), H * fmt.pitch, 1, o[frames - 1:].ctypes.data_as(_lib.f32p),
+                                                 a[frames - 1:].ctypes.data_as(_lib.f32p), C.byref(fst), None, C.c_void_p(st.cuda_stream)))
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(whole.reshape(H, fmt.pitch), full))
+    rays = float(W) * H * frames * steps
+    return {"workload": "BoxScene(10) 4096x4096 RGBX8, %d cameras of the rotation per call (configs[4])" % frames, "value": round(rays / wall / 1e6, 1),
+            "unit": "Mrays/s", "n_gpus": world, "ms_per_step": round(wall * 1e3 / steps, 4), "steps": steps, "frames_per_step": frames,
+            "tiling": ("%d-row bands round-robin over ranks" % band_rows) if world > 1 else "single GPU", "scaling": "strong",
+            "gather_ms_per_frame": None if gather_ms is None else round(gather_ms, 3), "gather_verified_equal_to_whole_frame": ok}
+
+
+def dropin_render(torch, ntracer_amd, tracern):
+    """The call the reference actually makes (obj_BlockingRenderer_render, src/render.cpp:853-909): ONE frame into a HOST buffer --
+    `BlockingRenderer().render(bytearray, format, scene)` at 1920x1080 RGBX8 -- kernel + D2H + every synchronisation, wall clock
+    per call; for BoxScene(6) and the 120-cell, cameras of the rotation set through the scene API as a render loop would.
+    `pipelined`: two scenes and two renderers on two host threads, frame k + 1 rendering while frame k's copy runs."""
+    import threading
+    W, H = 1920, 1080
+    fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(*c) for c in RGBX8])
+    G = os.path.join(ROOT, "tests", "golden")
+    res = {"what": "BlockingRenderer().render(bytearray, ImageFormat(1920, 1080, RGBX8), scene): one frame into host memory per call (kernel + D2H + syncs)"}
+
+    def measure(make_scene, cams_o, cams_a, frames, key):
+        sc = make_scene()
+        r = ntracer_amd.BlockingRenderer()
+        buf = bytearray(fmt.pitch * H)
+        for k in range(3):
+            sc._set_camera_arrays(cams_o[k], cams_a[k])
+            r.render(buf, fmt, sc)
+        t = []
+        for k in range(frames):
+            sc._set_camera_arrays(cams_o[k % len(cams_o)], cams_a[k % len(cams_o)])
+            t0 = time.perf_counter()
+            r.render(buf, fmt, sc)
+            t.append(time.perf_counter() - t0)
+        ms = float(np.median(t)) * 1e3
+        out = {"ms_per_frame": round(ms, 4), "best_ms": round(min(t) * 1e3, 4), "Mrays_s": round(W * H / ms / 1e3, 1), "frames": frames}
+        # pipelined: two scene handles (each has its own stream and device framebuffer), two threads, alternate frames
+        scs = [make_scene(), make_scene()]
+        rs = [ntracer_amd.BlockingRenderer(), ntracer_amd.BlockingRenderer()]
+        bufs = [bytearray(fmt.pitch * H), bytearray(fmt.pitch * H)]
+
+        def worker(i, count):
+            for k in range(count):
+                f = (2 * k + i) % len(cams_o)
+                scs[i]._set_camera_arrays(cams_o[f], cams_a[f])
+                rs[i].render(bufs[i], fmt, scs[i])
+        for i in (0, 1):
+            worker(i, 2)
+        th = [threading.Thread(target=worker, args=(i, frames // 2)) for i in (0, 1)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        ms2 = (time.perf_counter() - t0) * 1e3 / (2 * (frames // 2))
+        out["pipelined_ms_per_frame"] = round(ms2, 4)
+        out["pipelined_Mrays_s"] = round(W * H / ms2 / 1e3, 1)
+        res[key] = out
+
+    g = np.load(os.path.join(G, "box_n6_1920x1080.npz"))
+    measure(lambda: tracern.BoxScene(6), g["origins"], g["axes"], 60, "box6")
+    g4 = np.load(os.path.join(G, "cell120_n4.npz"))
+    measure(lambda: tracern.CompositeScene.from_flat(4, g4), g4["origins"], g4["axes"], 20, "cell120")
+    # the D2H copy of one such frame alone, to pinned memory (what the call cannot be faster than)
+    dev = torch.empty(fmt.pitch * H, dtype=torch.uint8, device="cuda")
+    host = torch.empty(fmt.pitch * H, dtype=torch.uint8).pin_memory()
+    torch.cuda.synchronize()
+    t = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        host.copy_(dev, non_blocking=True)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter() - t0)
+    res["d2h_alone_ms"] = round(min(t) * 1e3, 4)
+    return res
 
 
 def cpu_quota_cores():
@@ -402,6 +618,31 @@ def cpu_baseline(origins, axes, W, H):
     out["cpus_usable"] = quota
     for k in ("frames", "seconds"):
         out.pop(k, None)
+    # ---- the 120-cell (configs[3]) on the same cores: the reference's k-d walk restated (tracer.hpp:1179-1243 under
+    # render.cpp:829-838's thread rule), reference tree, cameras of the rotation, bounded to ~8 s
+    try:
+        g4 = np.load(os.path.join(ROOT, "tests", "golden", "cell120_n4.npz"))
+        flat = {k: g4[k] for k in ("root", "node_axis", "node_split", "node_left", "node_right", "items", "batch_recs", "batch_mats", "tri_recs",
+                                   "tri_mats", "solid_recs", "solid_types", "solid_mats", "materials", "aabb_start", "aabb_end")}
+        flat["batch_size"] = 4
+        sel = [0, 20, 40, 60, 80, 100, 120, 140]                    # the cameras the GPU figure (extra.cfg3_*) is timed on
+        r = ob.OracleRenderer(min(quota, online) - 1)
+        sc = ob.OracleScene(4, g4["origins"][0], g4["axes"][0], flat=flat)
+        t0 = time.perf_counter()
+        _, secs = r.render_frames(sc, W, H, RGBX8, g4["origins"][sel], g4["axes"][sel], 64, max_seconds=8.0)
+        total = time.perf_counter() - t0
+        out["cell120"] = {"value": round(W * H * len(secs) / total / 1e6, 3), "unit": "Mrays/s", "cores": r.threads, "kind": "port",
+                          "best_frame_Mrays_s": round(W * H / float(secs.min()) / 1e6, 3),
+                          "sample": "%d frames of the 1920x1080 {5/2,3,3} 120-cell (reference-built tree, the reference's walk) in one C call, %.1f s, %d threads"
+                                    % (len(secs), total, r.threads)}
+        r.close()
+    except Exception as e:          # a baseline never hides the headline
+        out["cell120"] = {"error": repr(e)[:200]}
+    # ---- how the port compares with the reference itself (measured where the reference can run: the build container)
+    try:
+        out["port_vs_reference"] = json.load(open(os.path.join(ROOT, "profiles", "port_vs_reference.json")))
+    except (OSError, ValueError):
+        out["port_vs_reference"] = None
     return out
 
 

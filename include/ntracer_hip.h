@@ -140,6 +140,13 @@ typedef struct {
                                     also for nt_colors_at / nt_calculate_color, which take no options. */
     int32_t collect_stats;       /* 1: count rays/nodes/tests with device atomics (slower) */
     int32_t reserved;
+    /* Abort for the device entry points (nt_render_device / nt_render_frames_device), which only enqueue: NULL, or a dword
+       the DEVICE can read while the kernels run -- best in device memory, raised by a 4-byte copy on another stream
+       (pinned host memory works too, but every block's look at it is then a PCIe round trip) -- that the caller sets
+       non-zero to cancel; blocks that have not started then leave without drawing (the reference polls its CANCEL state
+       per pixel, src/render.cpp:412).  nt_render keeps such a word itself and relays the caller's `abort_flag` to it;
+       this field is ignored there. */
+    const volatile int32_t *abort_device;
 } nt_render_opts;
 
 /* counters gathered when collect_stats is set (SURVEY section 8d byte model) */
@@ -188,8 +195,10 @@ int nt_scene_locked(const nt_scene_t *s);
 int nt_format_bytes_per_pixel(const nt_image_format *fmt);
 
 /* BlockingRenderer.render(dest, format, scene) (render.cpp:853-909): dest is HOST memory of at
-   least pitch*height bytes (or the compact size).  abort_flag (may be NULL) is polled between
-   slab launches; returns NT_ABORTED if it became non-zero (signal_abort, render.cpp:911-923). */
+   least pitch*height bytes (or the compact size).  abort_flag (may be NULL) is polled on the host
+   while the frame's one launch runs and relayed to a dword the kernels read when a block starts: blocks that have not
+   started leave without drawing.  Returns NT_ABORTED if the flag became non-zero before the frame was finished
+   (signal_abort, render.cpp:911-923); an aborted frame is not copied back -- `dest` stays as the caller had it. */
 int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format *fmt,
               const nt_render_opts *opts, volatile int *abort_flag);
 

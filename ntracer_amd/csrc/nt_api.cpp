@@ -20,6 +20,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ntracer_hip.h"
@@ -82,6 +83,13 @@ struct RowTable {
 struct DeviceState {
     int device = -1;
     hipStream_t stream = nullptr;        // used by the host-buffer entry points
+    // nt_render's abort: a dword in device memory (NtTarget::abort_word: read past the caches by every block that starts, a
+    // microsecond from HBM -- from mapped host memory the same read made a 120-cell frame four times as long) that the host
+    // raises, by a 4-byte copy on a stream of its own, when the caller's flag goes up; and the event the host waits on
+    DevBuf abort_word;
+    int *abort_one = nullptr;            // pinned source of that copy: the value 1
+    hipStream_t side_stream = nullptr;
+    hipEvent_t frame_done = nullptr;
     bool scene_uploaded = false;
     DevBuf nodes, items, batch_recs, batch_mats, tri_recs, tri_mats, solid_recs, solid_types, solid_mats, materials, aabb;
     DevBuf lights;                       // pl_pos | pl_color | gl_dir | gl_color
@@ -542,7 +550,8 @@ struct FrameJob {
     hipStream_t stream;
     bool stats;
     bool strict = false;      // nt_render_opts.strict_reference
-    int row_begin, row_count; // owned-row slab
+    const int *abort_word = nullptr;   // NtTarget::abort_word
+    int row_begin, row_count; // owned-row range
     // probe mode
     float *colors_out = nullptr;
     const int *xs = nullptr, *ys = nullptr;
@@ -599,6 +608,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         tg.row_begin = job.row_begin;
         tg.row_count = job.row_count;
         tg.aligned4 = ((uintptr_t)job.dest_dev % 4 == 0) && (f.pitch % 4 == 0) && (job.frame_stride % 4 == 0);
+        tg.abort_word = job.abort_word;
         if (tg.row_count <= 0 || f.bpp == 0) return NT_OK;      // nothing to draw
     }
     NtCamera cam;
@@ -963,6 +973,10 @@ void nt_scene_destroy(nt_scene_t *s) {
             if (st.done) (void)hipEventDestroy(st.done);
         }
         if (ds->stream) (void)hipStreamDestroy(ds->stream);
+        ds->abort_word.release();
+        if (ds->abort_one) (void)hipHostFree(ds->abort_one);
+        if (ds->side_stream) (void)hipStreamDestroy(ds->side_stream);
+        if (ds->frame_done) (void)hipEventDestroy(ds->frame_done);
     }
     delete s;
 }
@@ -1074,25 +1088,43 @@ int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format 
     job.stream = ds->stream;
     job.stats = stats;
     job.strict = opts && opts->strict_reference;
-    // abort is polled between slab launches (the reference polls per pixel, render.cpp:412)
-    const int slab = abort_flag ? std::max(64, (b.owned_rows + 7) / 8 / 16 * 16) : b.owned_rows;
-    bool aborted = false;
-    int rows_done = 0;
-    for (int r0 = 0; r0 < b.owned_rows; r0 += slab) {
-        if (abort_flag && *abort_flag) { aborted = true; break; }
-        job.row_begin = r0;
-        job.row_count = std::min(slab, b.owned_rows - r0);
-        if (int r = enqueue(s, ds, job)) { (void)hipStreamSynchronize(ds->stream); return r; }
-        if (abort_flag) HIP_TRY(hipStreamSynchronize(ds->stream));
-        rows_done = r0 + job.row_count;
+    // Abort (the reference's workers poll renderer::CANCEL per pixel, render.cpp:412): ONE launch for the frame -- cutting it
+    // into slabs cost a 120-cell frame a kernel tail per slab (9.3 ms instead of 1.2) -- whose blocks read a dword in device
+    // memory when they start, and the packet kernel's waves every few dozen nodes (NtTarget::abort_word).  The host waits for the
+    // frame with an eye on the caller's flag and raises that word when the flag goes up: what has not started leaves at once,
+    // so an abort costs what the waves in flight need to reach their next look at the word.  An aborted frame is incomplete
+    // in no particular order; nothing of it is copied back -- the caller's buffer stays as it was.
+    if (abort_flag) {
+        if (*abort_flag) return NT_ABORTED;
+        if (!ds->abort_one) {
+            if (int r = ds->abort_word.ensure(64)) return r;
+            void *p = nullptr;
+            HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocDefault));
+            ds->abort_one = (int *)p;
+            *ds->abort_one = 1;
+            HIP_TRY(hipStreamCreateWithFlags(&ds->side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ds->frame_done, hipEventDisableTiming));
+        }
+        HIP_TRY(hipMemsetAsync(ds->abort_word.p, 0, 4, ds->stream));
+        job.abort_word = (const int *)ds->abort_word.p;
     }
-    // an aborted render leaves the rows it did not reach as the caller had them (the reference's workers simply stop,
-    // render.cpp:412): only the finished slabs come back.  (Rows of a banded, non-compact frame are not contiguous;
-    // there the whole buffer -- initialised from `dest` above -- is returned.)
-    size_t back = need;
-    if (aborted && (b.world == 1 || b.compact)) back = (size_t)f.pitch * (size_t)rows_done;
-    if (back) HIP_TRY(hipMemcpyAsync(dest, ds->framebuffer.p, back, hipMemcpyDeviceToHost, ds->stream));
+    job.row_begin = 0;
+    job.row_count = b.owned_rows;
+    if (int r = enqueue(s, ds, job)) { (void)hipStreamSynchronize(ds->stream); return r; }
+    bool aborted = false;
+    if (abort_flag) {
+        HIP_TRY(hipEventRecord(ds->frame_done, ds->stream));
+        while (hipEventQuery(ds->frame_done) == hipErrorNotReady) {
+            if (!aborted && *abort_flag) {
+                (void)hipMemcpyAsync(ds->abort_word.p, ds->abort_one, 4, hipMemcpyHostToDevice, ds->side_stream);
+                aborted = true;
+            }
+            std::this_thread::yield();
+        }
+    }
+    if (!aborted && need) HIP_TRY(hipMemcpyAsync(dest, ds->framebuffer.p, need, hipMemcpyDeviceToHost, ds->stream));
     HIP_TRY(hipStreamSynchronize(ds->stream));
+    if (aborted) HIP_TRY(hipStreamSynchronize(ds->side_stream));
     if (stats) {
         unsigned long long v[8];
         HIP_TRY(hipMemcpy(v, ds->stats.p, sizeof(v), hipMemcpyDeviceToHost));
@@ -1100,7 +1132,6 @@ int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format 
         s->last_stats.simplex_tests = v[4]; s->last_stats.solid_tests = v[5]; s->last_stats.hits = v[6]; s->last_stats.aabb_enter = v[7];
         s->have_stats = true;
     }
-    if (abort_flag && *abort_flag) aborted = true;
     return aborted ? NT_ABORTED : NT_OK;
 }
 
@@ -1130,6 +1161,7 @@ int nt_render_device(nt_scene_t *s, void *dest_dev, size_t dest_len, const nt_im
     job.stream = (hipStream_t)hip_stream;
     job.stats = stats;
     job.strict = opts && opts->strict_reference;
+    job.abort_word = opts ? (const int *)opts->abort_device : nullptr;
     job.row_begin = 0;
     job.row_count = b.owned_rows;
     return enqueue(s, ds, job);
@@ -1189,6 +1221,7 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     job.stream = (hipStream_t)hip_stream;
     job.stats = stats;
     job.strict = opts && opts->strict_reference;
+    job.abort_word = opts ? (const int *)opts->abort_device : nullptr;
     job.row_begin = 0;
     job.row_count = b.owned_rows;
     return enqueue(s, ds, job);

@@ -1003,6 +1003,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     constexpr bool ALLIN = F32 || N <= NT_BOX_INLINE_MAX_N;
     constexpr bool SETS_LDS = ALLIN && N <= NT_BOX_SETS_MAX_N;
     __shared__ uint32_t s_sets[SETS_LDS ? 64 : 1];
+    __shared__ int s_abort;                  // the codes wave's reading of NtTarget::abort_word: one answer for the whole block
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1042,6 +1043,11 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     // ---- phase 1: the tile's stretch codes, one row per lane of one wave -- a different one from block to block, so that
     // the extra work does not always land on the same SIMD of a CU
     if (wv == (int)((blockIdx.x + blockIdx.y + frame) % (unsigned)WAVES)) {
+        if (tg.abort_word != nullptr) {
+            const bool ab = nt_aborted(tg);
+            if (WAVES == 1) { if (ab) return; }
+            else if (lane == 0) s_abort = ab ? 1 : 0;
+        }
         uint32_t code = 0u;
         uint32_t row_sets = 0u;
         // lane <-> slot tile_row0 + lane = row rr of wave w; interleaved: that wave's rr-th row is w + W * rr (NtTarget::row_il)
@@ -1088,6 +1094,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
         }
     }
     __syncthreads();
+    if (WAVES > 1 && tg.abort_word != nullptr && s_abort != 0) return;
 #ifdef NT_EXP_TRACE
     trace_t1 = wall_clock64();
 #endif

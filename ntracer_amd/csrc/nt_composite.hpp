@@ -1463,6 +1463,7 @@ __global__ __launch_bounds__(256) void composite_kernel_t(NtCameraFixed cam_in, 
     else { px = (wv & 1) * 8 + (lane & 7); py = (wv >> 1) * 8 + (lane >> 3); }
     const long long total = (long long)tiles_x * tiles_y * frames;
     for (long long tile = (long long)blockIdx.x; tile < total; tile += gridDim.x) {
+        if (nt_aborted(tg)) return;                       // (the four waves of a block are independent: no barrier below)
         const int bz = (int)(tile / ((long long)tiles_x * tiles_y));
         const int rem = (int)(tile - (long long)bz * tiles_x * tiles_y);
         const int by = rem / tiles_x;
@@ -1491,6 +1492,7 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
 template <int N, bool FEAT, bool STATS>
 __global__ __launch_bounds__(256) void composite_kernel(NtCameraFixed cam, NtCompositeDev sc, NtTarget tg) {
     extern __shared__ float2 lds_raw[];
+    if (nt_aborted(tg)) return;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wv = tid >> 6;
@@ -1554,6 +1556,7 @@ struct PersistArgs {
 template <int N>
 __global__ __launch_bounds__(256) void composite_persistent(NtCompositeDev sc, NtTarget tg, PersistArgs pa) {
     extern __shared__ float2 lds_raw[];
+    if (nt_aborted(tg)) return;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wv = tid >> 6;
@@ -1842,6 +1845,7 @@ __device__ __forceinline__ bool wm_claim(int *wm, int lane, int item, bool activ
 template <int N, int DEPTH, bool FEAT, bool SCAL>
 __global__ __launch_bounds__(256, FEAT ? 1 : ((N <= 4 && !SCAL) ? 6 : (N <= 7 ? 5 : 4))) void composite_packet(NtCompositeDev sc, NtTarget tg, PacketArgs pa) {
     extern __shared__ float2 lds_raw[];
+    if (nt_aborted(tg)) return;                           // (four independent waves: no barrier in this kernel)
     const int lane = (int)threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 #ifdef NT_EXP_TRACE
@@ -2058,6 +2062,9 @@ __global__ __launch_bounds__(256, FEAT ? 1 : ((N <= 4 && !SCAL) ? 6 : (N <= 7 ? 
         if (sp == 0) break;
         --sp;
         const int far = __builtin_amdgcn_readfirstlane(ustack[sp * 8 + 0]);
+        // (abort: a look at the word on one pop in 64 -- by the node id, which costs no counter -- so that a wave on one of
+        // the long walks through the middle of a scene does not hold an aborted frame for milliseconds)
+        if (tg.abort_word != nullptr && (far & 63) == 0 && nt_aborted(tg)) return;
         const unsigned long long m = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 8 + 2]) << 32) |
                                      (unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 8 + 1]);
         const bool was_both = ((bothbits >> sp) & 1u) != 0u;

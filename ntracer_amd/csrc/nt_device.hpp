@@ -76,6 +76,10 @@ struct NtTarget {
     // w + 2W, ... -- every wave of a strip then holds the same share of the rows that need ray-by-ray work -- and the row
     // table is in SLOT order: entry w * ROWS + rr belongs to row w + W * rr (valid = 0 past the last row).
     int row_il;
+    // Abort word (renderer::CANCEL, polled per pixel by the reference: render.cpp:412): nullptr, or a device-visible dword --
+    // pinned host memory mapped into the device's address space -- that the kernels read past the caches when a block (or a
+    // tile of a striding block) starts; non-zero: the block leaves without drawing
+    const int *abort_word;
     // box_tile_kernel: the middle columns of the image are started `lead_frames` frames ahead of the outer ones (see the kernel); 0: off
     int lead_frames;
 };

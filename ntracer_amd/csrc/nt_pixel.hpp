@@ -21,6 +21,12 @@ char *nt_launch_error_buf();
 
 namespace {
 
+// has the caller raised the abort flag?  (NtTarget::abort_word: a system-scope load, past L1 / L2 -- the word lives in host
+// memory and is written by the host while the kernel runs; every lane reads the same address)
+__device__ __forceinline__ bool nt_aborted(const NtTarget &tg) {
+    return tg.abort_word != nullptr && __hip_atomic_load(tg.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+}
+
 // --------------------------------------------------------------------------------------
 // pixel packing: render.cpp:419-462
 // --------------------------------------------------------------------------------------

@@ -1477,6 +1477,7 @@ __global__ __launch_bounds__(64) void composite_kernel_var_t(NtCamera cam, NtCom
     const VarCtx cx = {sc, L, w, n, lane};
     const long long total = (long long)tiles_x * tiles_y * frames;
     for (long long tile = (long long)blockIdx.x; tile < total; tile += gridDim.x) {
+        if (nt_aborted(tg)) return;                       // (one wave a block)
         const int bz = (int)(tile / ((long long)tiles_x * tiles_y));
         const int rem = (int)(tile - (long long)bz * tiles_x * tiles_y);
         const int by = rem / tiles_x;
@@ -1511,6 +1512,7 @@ __global__ __launch_bounds__(64) void composite_kernel_var_t(NtCamera cam, NtCom
 
 __global__ __launch_bounds__(64) void composite_kernel_var(NtCamera cam, NtCompositeDev sc, NtTarget tg, int n) {
     extern __shared__ float2 lds_raw[];
+    if (nt_aborted(tg)) return;
     const int lane = (int)threadIdx.x;
     const int depth = sc.stack_depth;
     VarLds L;

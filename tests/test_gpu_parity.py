@@ -1337,10 +1337,10 @@ def test_abort_flag_set_before_the_call_renders_nothing():
     assert not sc.locked
 
 
-def test_signal_abort_stops_a_running_render_within_a_slab():
-    """The flag goes up from another thread as soon as the render holds the scene: render() returns False, at least one
-    whole slab at the bottom of the image was never drawn (the sentinel bytes are still there), what was drawn is a whole
-    number of slabs with the right pixels, and the scene is unlocked again."""
+def test_signal_abort_stops_a_running_render():
+    """The flag goes up from another thread as soon as the render holds the scene: render() returns False well before a full
+    frame's time has passed (the kernels read the abort word when a block starts: what is in flight finishes, the rest leaves),
+    nothing of the incomplete frame is copied back -- the caller's buffer is as it was -- and the scene is unlocked again."""
     import threading
     import time
     sc, fmt = _long_scene()
@@ -1351,7 +1351,6 @@ def test_signal_abort_stops_a_running_render_within_a_slab():
     t0 = time.perf_counter()
     assert r.render(full, fmt, sc, strict_reference=True) is True
     t_full = time.perf_counter() - t0
-    full = np.frombuffer(bytes(full), np.uint8).reshape(H, pitch)
 
     buf = bytearray(b"\xab" * (pitch * H))
     out = {}
@@ -1364,22 +1363,66 @@ def test_signal_abort_stops_a_running_render_within_a_slab():
     t.start()
     while not sc.locked and t.is_alive():
         pass
-    time.sleep(0.3 * t_full)                     # somewhere in the middle of the eight slabs
+    time.sleep(0.3 * t_full)                     # somewhere in the middle of the frame
     t_sig = time.perf_counter()
     r.signal_abort()
     t.join()
     assert out["ok"] is False
     assert not sc.locked
-    img = np.frombuffer(bytes(buf), np.uint8).reshape(H, pitch)
-    untouched = (img == 0xab).all(axis=1)
-    rows = int(np.argmax(untouched)) if untouched.any() else H            # first row that was never drawn
-    slab = max(64, (H + 7) // 8 // 16 * 16)                              # nt_render's polling granularity
-    assert rows < H and rows % slab == 0, rows
-    assert untouched[rows:].all()
-    assert np.array_equal(img[:rows], full[:rows])
-    # after the flag went up: the slab in flight, then the copy of what was finished -- well under half a frame
-    assert out["end"] - t_sig < 0.5 * t_full, (out["end"] - t_sig, t_full, rows)
-    assert r.render(buf, fmt, sc) is True        # state is reset at the start of the next render (render.cpp:889)
+    assert bytes(buf) == b"\xab" * len(buf)
+    # after the flag went up: the waves in flight -- well under half a frame
+    assert out["end"] - t_sig < 0.5 * t_full, (out["end"] - t_sig, t_full)
+    assert r.render(buf, fmt, sc, strict_reference=True) is True        # state is reset at the start of the next render (render.cpp:889)
+    assert bytes(buf) == bytes(full)
+
+
+def test_abort_word_on_the_batched_device_path():
+    """nt_render_opts.abort_device: the device entry points only enqueue, so their abort is a dword the device can read while
+    the kernels run (here: device memory).  Raised before the call: no block draws -- every frame keeps its sentinel bytes;
+    lowered again: the same call renders the frames."""
+    import torch
+    g = fx.load("box_n6_1920x1080")
+    sc = tracern.BoxScene(6)
+    fmt = fmt_of(1920, 1080, fx.RGBX8)
+    fst = fmt._as_struct()
+    F = 8
+    word = torch.zeros(16, dtype=torch.int32, device="cuda")
+    opts = _lib.NtRenderOpts()
+    opts.device = -1
+    opts.band_world = 1
+    opts.abort_device = word.data_ptr()
+    o = np.ascontiguousarray(g["origins"][:F], np.float32)
+    a = np.ascontiguousarray(g["axes"][:F], np.float32)
+    fb = torch.full((F, fmt.pitch * 1080), 0xab, dtype=torch.uint8, device="cuda")
+
+    def go():
+        _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), fmt.pitch * 1080, F, o.ctypes.data_as(_lib.f32p),
+                                                      a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts),
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+    word.fill_(1)
+    torch.cuda.synchronize()
+    go()
+    assert bool((fb == 0xab).all())
+    word.fill_(0)
+    torch.cuda.synchronize()
+    go()
+    ref = ob.OracleScene(6, o[3], a[3]).render(1920, 1080, fx.RGBX8, threads=8)
+    assert np.array_equal(fb[3].cpu().numpy().reshape(1080, fmt.pitch), ref)
+    # ... and the 120-cell's packet kernel the same way
+    g4 = fx.load("cell120_n4")
+    sc4 = tracern.CompositeScene.from_flat(4, fx.flat_of(g4))
+    o4 = np.ascontiguousarray(g4["origins"][:2], np.float32)
+    a4 = np.ascontiguousarray(g4["axes"][:2], np.float32)
+    fmt4 = fmt_of(640, 360, fx.RGBX8)
+    fst4 = fmt4._as_struct()
+    fb4 = torch.full((2, fmt4.pitch * 360), 0xab, dtype=torch.uint8, device="cuda")
+    word.fill_(1)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().nt_render_frames_device(sc4._handle, C.c_void_p(fb4.data_ptr()), fmt4.pitch * 360, 2, o4.ctypes.data_as(_lib.f32p),
+                                                  a4.ctypes.data_as(_lib.f32p), C.byref(fst4), C.byref(opts), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert bool((fb4 == 0xab).all())
 
 
 def test_second_render_on_a_busy_renderer_or_scene_is_refused():
