@@ -202,6 +202,9 @@ int nt_format_bytes_per_pixel(const nt_image_format *fmt);
 int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format *fmt,
               const nt_render_opts *opts, volatile int *abort_flag);
 
+/* (Streams: the launches of one scene on one device share that scene's scratch buffers and are ordered by the stream they
+   are enqueued on.  A call that names another stream than the scene's previous call on that device first waits, on the
+   host, for the previous stream to drain -- alternate streams per scene handle, not within one.) */
 /* Same frame loop, but dest is DEVICE memory on opts->device and the launch is only enqueued on
    `hip_stream` (a hipStream_t; NULL = the legacy default stream); no host synchronisation.  Used
    by the bench (framebuffer resident in HBM) and by the multi-GPU gather.  The scene must stay

@@ -156,6 +156,11 @@ def lib():
                 "libntracer_hip.so is missing (%s): build it with `python -m ntracer_amd.build` "
                 "(hipcc --offload-arch=gfx950).  The ray-cast path has no CPU fallback." % LIB_PATH)
         _preload_torch_hip_runtime()
+        if os.environ.get("NTRACER_HIP_LIB"):
+            # an A/B or ablation build stands in for the product: say so, every time (a stale variable on a bench box would
+            # otherwise be measured as if it were the library)
+            import sys
+            sys.stderr.write("ntracer_amd: NTRACER_HIP_LIB is set -- loading %s instead of the in-tree libntracer_hip.so\n" % LIB_PATH)
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(l, name)      # AttributeError if the ABI is incomplete

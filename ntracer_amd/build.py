@@ -56,7 +56,11 @@ def _flag_tag():
 
 
 PYBUF_SRC = os.path.join(CSRC, "nt_pybuffer.c")
-PYBUF_OUT = os.path.join(HERE, "_pybuffer.so")
+# named with the interpreter's ABI tag (_pybuffer.cpython-310-x86_64-linux-gnu.so): a prebuilt copy that travels to a box
+# with another CPython is then simply not found -- render.py falls back to `object` -- instead of being dlopened against
+# the wrong PyTypeObject layout
+import sysconfig as _sysconfig
+PYBUF_OUT = os.path.join(HERE, "_pybuffer" + (_sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 
 def build_pybuffer(force=False, verbose=False):
@@ -96,12 +100,21 @@ def build(force=False, verbose=False, out=None):
         jobs.sort(key=lambda c: 0 if "nt_inst_composite.hip" in c[-3] else 1)
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(out, objs):
+    # the flags the library was last linked from, beside it: a default build after an ablation build (NTRACER_HIPCC_FLAGS) finds
+    # its own objects up to date, and would otherwise leave the ablation library in place
+    tagfile = out + ".tag"
+    try:
+        linked_tag = open(tagfile).read().strip()
+    except OSError:
+        linked_tag = ""
+    if jobs or force or linked_tag != tag or _stale(out, objs):
         cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", out + ".tmp"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         os.replace(out + ".tmp", out)
+        with open(tagfile, "w") as fh:
+            fh.write(tag + "\n")
     return out
 
 

@@ -83,6 +83,11 @@ struct RowTable {
 struct DeviceState {
     int device = -1;
     hipStream_t stream = nullptr;        // used by the host-buffer entry points
+    // The per-device scratch of a scene (camera table, BoxScene's redo bitmap, hit records ...) is shared by its launches, which
+    // are ordered by their stream.  A call that arrives on another stream than the one before first waits (on the host) for
+    // that stream to drain: see use_stream
+    hipStream_t last_stream = nullptr;
+    bool have_last_stream = false;
     // nt_render's abort: a dword in device memory (NtTarget::abort_word: read past the caches by every block that starts, a
     // microsecond from HBM -- from mapped host memory the same read made a 120-cell frame four times as long) that the host
     // raises, by a 4-byte copy on a stream of its own, when the caller's flag goes up; and the event the host waits on
@@ -96,6 +101,7 @@ struct DeviceState {
     unsigned long long lights_version = 0;
     DevBuf framebuffer, cams, probes, stats, counter;
     DevBuf hits;                         // primary-hit records between the two passes of a lit render
+    DevBuf stats_frame;                  // where the statistics launch of a "faithful" scene draws (discarded)
     DevBuf numer;                        // packet kernel: -(N.o + d) per (frame, simplex)
     DevBuf cull;                         // BoxScene: row culling bits
     bool cull_clean = false;             // `cull` is all zero (what the fused BoxScene path needs and leaves behind)
@@ -298,6 +304,14 @@ int device_state(nt_scene *s, int dev, DeviceState *&out) {
         it = s->devs.emplace(dev, std::move(ds)).first;
     }
     out = it->second.get();
+    return NT_OK;
+}
+
+// launches of one scene on one device are ordered by their stream; when the stream changes, the old one is drained first
+int use_stream(DeviceState *ds, hipStream_t st) {
+    if (ds->have_last_stream && ds->last_stream != st) HIP_TRY(hipStreamSynchronize(ds->last_stream));
+    ds->last_stream = st;
+    ds->have_last_stream = true;
     return NT_OK;
 }
 
@@ -551,6 +565,7 @@ struct FrameJob {
     bool stats;
     bool strict = false;      // nt_render_opts.strict_reference
     const int *abort_word = nullptr;   // NtTarget::abort_word
+    bool counters_pass = false;        // (enqueue's own) the statistics launch of a scene whose pixels come from the faithful kernels
     int row_begin, row_count; // owned-row range
     // probe mode
     float *colors_out = nullptr;
@@ -559,7 +574,31 @@ struct FrameJob {
     int view_w = 0, view_h = 0;
 };
 
-int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
+int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job_in) {
+    FrameJob job = job_in;
+    if (s->composite && job.stats && !job.counters_pass && !job.colors_out) {
+        // Scenes with transparent materials or Solids are drawn by the kernels that reproduce the reference's o_hit.normal
+        // handling (below), which keep no counters.  Asking for statistics must not change the pixels: the frame is drawn as
+        // always, and the counters come from a launch of their own -- the counting kernel (a hit keeps the normal of what
+        // was hit, 16-slot mailbox) into a scratch frame.  They describe THAT traversal: the same tree and cells, a few
+        // repeated tests after mailbox evictions.  Transparent materials have no counting kernel at all: refused.
+        if (s->n > NT_MAX_FIXED_DIM) return fail(NT_E_UNSUPPORTED, "collect_stats is not available above %d dimensions (the run-time-n kernels keep no counters)", NT_MAX_FIXED_DIM);
+        const char *ecl0 = getenv("NTRACER_CLEAN_NORMALS");
+        const bool clean0 = ecl0 && atoi(ecl0) != 0;
+        if (!s->all_opaque)
+            return fail(NT_E_UNSUPPORTED, "collect_stats is not available for scenes with transparent materials (their kernels keep no counters)");
+        if (s->n_solids > 0 && !clean0) {
+            const size_t bytes = (size_t)job.fmt->pitch * (size_t)(job.bands.compact ? job.bands.owned_rows : job.fmt->height);
+            if (int e = ds->stats_frame.ensure(std::max<size_t>(bytes, 16))) return e;
+            FrameJob cj = job;
+            cj.counters_pass = true;
+            cj.dest_dev = ds->stats_frame.p;
+            cj.frame_stride = 0;
+            if (job.nframes > 1) return fail(NT_E_UNSUPPORTED, "collect_stats on a multi-frame launch is not available for scenes with Solids");
+            if (int e = enqueue(s, ds, cj)) return e;
+            job.stats = false;
+        }
+    }
     NtTarget tg;
     std::memset(&tg, 0, sizeof(tg));
     if (job.colors_out) {
@@ -653,7 +692,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job) {
         // lane.  NTRACER_CLEAN_NORMALS=1 selects the intended semantics instead (a hit keeps the normal of what was hit).
         const char *ecl = getenv("NTRACER_CLEAN_NORMALS");
         const bool clean = ecl && atoi(ecl) != 0;
-        const bool faithful = !s->all_opaque || (s->n_solids > 0 && !clean && !job.stats);
+        const bool faithful = !job.counters_pass && (!s->all_opaque || (s->n_solids > 0 && !clean));
         if (faithful) {
             // (transparent materials need the exact list in either mode: the reference trims its transparent hits with the
             // distance of the LAST test, so a repeated test is not harmless there)
@@ -963,7 +1002,7 @@ void nt_scene_destroy(nt_scene_t *s) {
         (void)hipDeviceSynchronize();
         for (DevBuf *b : {&ds->nodes, &ds->items, &ds->batch_recs, &ds->batch_mats, &ds->tri_recs, &ds->tri_mats, &ds->solid_recs,
                           &ds->solid_types, &ds->solid_mats, &ds->materials, &ds->aabb, &ds->lights, &ds->framebuffer, &ds->cams, &ds->counter,
-                          &ds->probes, &ds->stats, &ds->hits, &ds->numer, &ds->cull, &ds->checked, &ds->tframes, &ds->ties})
+                          &ds->probes, &ds->stats, &ds->hits, &ds->stats_frame, &ds->numer, &ds->cull, &ds->checked, &ds->tframes, &ds->ties})
             b->release();
         for (auto &t : ds->chan_tables) if (t->dev) (void)hipFree(t->dev);
         for (auto &t : ds->row_tables) if (t->dev) (void)hipFree(t->dev);
@@ -1072,6 +1111,7 @@ int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format 
     DeviceState *ds;
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
+    if (int r = use_stream(ds, ds->stream)) return r;
     if (int r = ds->framebuffer.ensure(std::max<size_t>(need, 16))) return r;
     const bool stats = opts && opts->collect_stats;
     if (int r = prepare_stats(ds, ds->stream, stats)) return r;
@@ -1150,6 +1190,7 @@ int nt_render_device(nt_scene_t *s, void *dest_dev, size_t dest_len, const nt_im
     DeviceState *ds;
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
+    if (int r = use_stream(ds, (hipStream_t)hip_stream)) return r;
     const bool stats = opts && opts->collect_stats;
     if (int r = prepare_stats(ds, (hipStream_t)hip_stream, stats)) return r;
     if (stats) { s->have_stats = false; s->stats_device = dev; }
@@ -1184,6 +1225,7 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     DeviceState *ds;
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
+    if (int r = use_stream(ds, (hipStream_t)hip_stream)) return r;
     const int n = s->n;
     const size_t cam_floats = (size_t)nframes * 4 * n + (size_t)nframes * 4;
     DeviceState::Stage *st = nullptr;
@@ -1239,6 +1281,7 @@ int nt_colors_at(nt_scene_t *s, int width, int height, int count, const int32_t 
     DeviceState *ds;
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
+    if (int r = use_stream(ds, ds->stream)) return r;
     const size_t ibytes = (size_t)count * sizeof(int32_t);
     const size_t cbytes = (size_t)count * 3 * sizeof(float);
     if (int r = ds->probes.ensure(2 * ibytes + cbytes)) return r;

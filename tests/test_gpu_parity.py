@@ -1312,6 +1312,105 @@ def test_shadow_rays_are_counted():
     assert st["shadow_rays"] > 0 and st["rays"] > 96 * 64      # primary + reflection
 
 
+@pytest.mark.parametrize("n", [3, 6, 8, 10])
+def test_box_soak_slice(n):
+    """A slice of tools/box_soak.py in the suite: 24 random cameras per dimension at full 1920x1080 -- orthonormal frames at
+    distances 1.2 .. 12 from the cube, off-axis, every seventh on a diagonal (coordinates equal up to rounding, like the demo's
+    camera path: whole regions of near-ties between faces) -- one multi-frame launch per format, RGBX8 and three fp32
+    channels, every frame byte for byte against the oracle.  This is what exercises the guard arithmetic of the tile
+    kernel's lean loops (nt_box.hpp: the rsq quantisation's 2^-18 guard, the stretch codes' margins) beyond the 160 scripted
+    cameras."""
+    import torch
+    import bench
+    W, H, F = 1920, 1080, 24
+    threads = max(1, min(64, bench.cpu_quota_cores() - 1))
+    rng = np.random.default_rng(20260 + n)
+    origins, axes = [], []
+    for k in range(F):
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        q = np.ascontiguousarray(q, np.float32)
+        dist = float(rng.choice([1.2, 1.6, 2.5, 4.0, 7.0, 12.0]))
+        o = -q[2] * np.float32(dist) + np.float32(rng.uniform(-0.6, 0.6)) * q[0] + np.float32(rng.uniform(-0.6, 0.6)) * q[1]
+        if k % 7 == 0:
+            o = np.full(n, -dist / np.sqrt(n), np.float32)
+            q = q.copy()
+            q[2] = -o / np.linalg.norm(o)
+        origins.append(o.astype(np.float32))
+        axes.append(q)
+    o = np.ascontiguousarray(np.stack(origins), np.float32)
+    a = np.ascontiguousarray(np.stack(axes), np.float32)
+    sc = tracern.BoxScene(n)
+    osc = ob.OracleScene(n, o[0], a[0])
+    for chans in (fx.RGBX8, fx.RGBF32):
+        fmt = fmt_of(W, H, chans)
+        fst = fmt._as_struct()
+        fb = torch.zeros((F, H * fmt.pitch), dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), H * fmt.pitch, F, o.ctypes.data_as(_lib.f32p),
+                                                      a.ctypes.data_as(_lib.f32p), C.byref(fst), None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        got = fb.cpu().numpy().reshape(F, H, fmt.pitch)
+        for f in range(F):
+            osc.set_camera(o[f], a[f])
+            ref = osc.render(W, H, chans, threads=threads)
+            assert np.array_equal(got[f], ref), (n, f, fmt.bytes_per_pixel, int((got[f] != ref).sum()))
+
+
+def test_box_kernel_paths_alternate_on_one_scene(monkeypatch):
+    """The packed-RGB formats normally take the fused tile kernel; NTRACER_BOX_PATH=0 selects the older cull -> box -> redo
+    kernels, which share the scene's scratch buffer with it (the fused path keeps a bitmap there that must be all zero between
+    launches).  The same frames on ONE scene through path 0, the fused path and path 0 again -- and the fused path with rows
+    interleaved and not -- byte for byte like the oracle, in 6 and in 10 dimensions (with and without a second kernel)."""
+    import torch
+    for n, name, W, H in ((6, "box_n6_1920x1080", 1920, 1080), (10, "box_n10_4096x4096", 1024, 640)):
+        g = fx.load(name)
+        sel = [3, 47, 101]
+        o = np.ascontiguousarray(g["origins"][sel], np.float32)
+        a = np.ascontiguousarray(g["axes"][sel], np.float32)
+        fmt = fmt_of(W, H, fx.RGBX8)
+        fst = fmt._as_struct()
+        refs = [ob.OracleScene(n, o[k], a[k]).render(W, H, fx.RGBX8, threads=8) for k in range(len(sel))]
+        sc = tracern.BoxScene(n)
+        fb = torch.empty((len(sel), fmt.pitch * H), dtype=torch.uint8, device="cuda")
+        for path, il in (("0", None), (None, None), ("0", None), (None, "0"), (None, None), ("0", None)):
+            if path is None:
+                monkeypatch.delenv("NTRACER_BOX_PATH", raising=False)
+            else:
+                monkeypatch.setenv("NTRACER_BOX_PATH", path)
+            if il is None:
+                monkeypatch.delenv("NTRACER_BOX_INTERLEAVE", raising=False)
+            else:
+                monkeypatch.setenv("NTRACER_BOX_INTERLEAVE", il)
+            fb.fill_(0x5a)
+            _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), fmt.pitch * H, len(sel), o.ctypes.data_as(_lib.f32p),
+                                                          a.ctypes.data_as(_lib.f32p), C.byref(fst), None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            got = fb.cpu().numpy().reshape(len(sel), H, fmt.pitch)
+            for k in range(len(sel)):
+                assert np.array_equal(got[k], refs[k]), (n, path, il, k, int((got[k] != refs[k]).sum()))
+
+
+def test_asking_for_statistics_does_not_change_the_pixels():
+    """collect_stats on a scene with Solids: the frame still comes from the kernel that reproduces the reference's normal
+    handling (the counters from a launch of their own); on a scene with transparent materials -- whose kernels keep no
+    counters -- it is refused instead of reporting nothing."""
+    g = fx.load("feature3d")
+    flat = fx.flat_of(g, opaque=True)
+    sc = tracern.CompositeScene.from_flat(3, flat)
+    sc._set_camera_arrays(g["origin"], g["axes"])
+    sc.set_params_flat(fx.params_of(g, "shadows__"))
+    fmt = fmt_of(96, 64, fx.RGBF32)
+    plain = render_host(sc, fmt)
+    counted = render_host(sc, fmt, collect_stats=True)
+    assert np.array_equal(plain, counted)
+    st = sc.last_stats()
+    assert st["rays"] > 96 * 64 and st["solid_tests"] > 0
+    tr = tracern.CompositeScene.from_flat(3, fx.flat_of(g))            # the fixture as it is: transparent materials
+    tr._set_camera_arrays(g["origin"], g["axes"])
+    with pytest.raises(NotImplementedError, match="collect_stats"):
+        render_host(tr, fmt, collect_stats=True)
+    assert not tr.locked
+
+
 # ------------------------------------------------------------------ renderer protocol
 def _long_scene():
     """the 120-cell walked strictly at 4096x4096: eight slabs of a few milliseconds each"""
