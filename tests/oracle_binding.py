@@ -54,7 +54,9 @@ def lib():
     if _LIB is None:
         path = os.path.join(ORACLE_DIR, "libntracer_oracle.so")
         src = os.path.join(ORACLE_DIR, "ntracer_oracle.c")
-        if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+        if os.environ.get("NTRACER_ORACLE_LIB"):        # tools/sanitize.sh: the same source built with -fsanitize=...
+            path = os.environ["NTRACER_ORACLE_LIB"]
+        elif not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
             build()
         _LIB = C.CDLL(path)
         _LIB.nto_calculate_color.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_int, C.c_int, f32p]
