@@ -44,8 +44,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 STORE_ONLY_GBS = 5650.0       # 64 x 64-pixel tiles, 256 bytes per store instruction: tools/micro/store_rate.hip on MI355X
 SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
-CLOCK_GHZ = 2.4                # max clock (MI355X_MICROARCH.md)
-PROFILE = "r02_pmc_summary.json"       # profiles/: rocprofv3 --pmc passes of THIS build (tools/profile_round.sh)
+PROFILE = "r03_pmc_summary.json"       # profiles/: rocprofv3 --pmc passes of THIS build (tools/profile_round.sh)
 RGBX8 = [(8, 1, 0, 0), (8, 0, 1, 0), (8, 0, 0, 1), (8, 0, 0, 0)]
 RGBF32 = [(32, 1, 0, 0, 0, True), (32, 0, 1, 0, 0, True), (32, 0, 0, 1, 0, True)]
 
@@ -58,30 +57,29 @@ def load_profile():
 
 
 def valu_bound(call, measured_us):
-    """The instruction-issue bound of a call from the committed SQ counters: VALU (+ scalar) wave-instructions per call, the
-    time they need at the full fp32 rate -- one VALU wave-instruction per SIMD every 2 cycles at 2.4 GHz, which is what the
-    157 TFLOP/s spec figure means for wave64 -- and that time as a fraction of the measured one."""
-    if not call or "valu_wave_insts_per_call" not in call and "SQ_INSTS_VALU" not in call:
+    """The instruction-issue bound of a call from the committed rocprofv3 passes (profiles/<PROFILE>, tools/profile_round.sh):
+    VALU wave-instructions by class (SQ_INSTS_VALU_ADD_F32 / MUL / FMA / TRANS / INT32 / INT64 / CVT, rest = total - these),
+    priced with the issue costs tools/micro/valu_rate2.hip measures on this part -- 2 cycles per SIMD for full-rate arithmetic,
+    4 for the half-rate instructions (compares, selects, min / max, cvt, fract, perm ...), 8 for transcendentals; INT32 and the
+    rest are mixtures and are priced at 2 (`lo`) and at 4 (`hi`) -- against the kernel's own cycle count from the same profile
+    (GRBM_GUI_ACTIVE / 8).  Cycles against cycles: no clock enters."""
+    if not call:
         return None
+    lo = call.get("issue_cycles_per_simd_lo")
+    hi = call.get("issue_cycles_per_simd_hi")
+    cyc = call.get("kernel_cycles_per_call", call.get("kernel_cycles"))
     valu = call.get("valu_wave_insts_per_call", call.get("SQ_INSTS_VALU"))
+    if not lo or not hi or not cyc:
+        return None
     salu = call.get("salu_wave_insts_per_call", call.get("SQ_INSTS_SALU"))
-    active = call.get("valu_active_quad_cycles_per_call", call.get("SQ_ACTIVE_INST_VALU"))
-    cycles = call.get("kernel_cycles_per_call", call.get("kernel_cycles"))
-    limited_us = valu / SIMDS * 2.0 / (CLOCK_GHZ * 1e3)
-    out = {"valu_wave_insts": round(valu), "salu_wave_insts": round(salu) if salu else None,
-           "peak": "1 VALU wave-instruction / SIMD / 2 cycles @ 2.4 GHz (= 157 TFLOP/s fp32)", "issue_limited_us": round(limited_us, 2),
-           "measured_us": round(measured_us, 2), "frac": round(limited_us / measured_us, 4),
-           "source": "profiles/" + PROFILE}
-    # ... and at the rate non-packed wave64 instructions can actually issue on a 16-lane SIMD, one per 4 cycles
-    # (v_pk_fma_f32 is the only way to the spec rate; the kernels' average is 4.2 cycles per instruction)
-    out["issue_limited_us_wave64"] = round(2.0 * limited_us, 2)
-    out["frac_wave64"] = round(2.0 * limited_us / measured_us, 4)
-    if active and cycles:
-        # SQ_ACTIVE_INST_VALU: quad-cycles in which a SIMD's VALU was executing (MI355X_MICROARCH.md); half-rate and
-        # transcendental instructions (v_cndmask, v_perm, v_cvt, v_rsq ...) hold it 4 - 8 cycles, cf. tools/micro/valu_rate.hip
-        out["valu_busy_frac_profiled"] = round(active * 4.0 / SIMDS / cycles, 4)
-        out["cycles_per_valu_inst_profiled"] = round(active * 4.0 / valu, 3)
-    return out
+    return {"valu_wave_insts": round(valu), "salu_wave_insts": round(salu) if salu else None, "by_class": call.get("valu_by_class"),
+            "price_cycles_per_wave_inst_per_simd": {"full rate (ADD/MUL/FMA f32)": 2, "TRANS f32": 8, "CVT": 4, "INT32, rest: lo": 2, "INT32, rest: hi": 4},
+            "issue_limited_cycles_per_simd": [round(lo), round(hi)], "kernel_cycles_profiled": round(cyc),
+            "frac_lo": round(lo / cyc, 4), "frac_hi": round(hi / cyc, 4), "frac": round(0.5 * (lo + hi) / cyc, 4),
+            "issue_limited_us": [round(measured_us * lo / cyc, 1), round(measured_us * hi / cyc, 1)], "measured_us": round(measured_us, 2),
+            "note": "frac = issue-limited cycles / kernel cycles, both from the profile (lo: every instruction of the mixed classes at the full "
+                    "rate; hi: at half rate; frac: their mean); issue_limited_us scales the live launch time by the same ratios",
+            "source": "profiles/" + PROFILE}
 
 
 def main():
@@ -404,8 +402,10 @@ def value_rgbf32(torch, ntracer_amd, tracern, _lib, origins, axes, F):
     fmt = ntracer_amd.ImageFormat(1920, 1080, [ntracer_amd.Channel(*c) for c in RGBF32])
     ms = _time_frames(torch, _lib, tracern.BoxScene(6), fmt, origins, axes, F, 10)
     rays = 1920 * 1080 * F
+    prof = load_profile()
     return {"value": round(rays / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_step": round(ms, 5), "bytes_per_ray": 12,
             "hbm_write_GBs": round(rays * 12 / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(rays * 12 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "valu": valu_bound(prof.get("rgbf32_call"), ms * 1e3) if prof and F == 160 else None,
             "workload": "BoxScene(6) 1920x1080, three fp32 channels, the same %d-frame sequence, one call per step" % F}
 
 
@@ -723,6 +723,19 @@ def extra_configs(torch, ntracer_amd, tracern, _lib):
     res["cfg3_shadows_960x540"] = {"primary_rays": st["rays"], "shadow_rays": st["shadow_rays"],
                                       "Mrays_s_primary_plus_shadow": round((st["rays"] + st["shadow_rays"]) / ms2 / 1e3, 1),
                                       "ms_per_frame": round(ms2, 3)}
+    # ... and at the headline's size, eight cameras a call (rays counted on frame 0 by a statistics render)
+    fmt3 = ntracer_amd.ImageFormat(1920, 1080, chan)
+    buf = bytearray(fmt3.pitch * 1080)
+    ntracer_amd.BlockingRenderer().render(buf, fmt3, sc, collect_stats=True)
+    st = sc.last_stats()
+    ms3 = time_scene(sc, fmt3, g["origins"][sel], g["axes"][sel], 8, 2)
+    res["cfg3_shadows_1080p"] = {"primary_rays": st["rays"], "shadow_rays": st["shadow_rays"],
+                                    "Mrays_s_primary_plus_shadow": round((st["rays"] + st["shadow_rays"]) / ms3 / 1e3, 1),
+                                    "ms_per_frame": round(ms3, 3), "frames_per_call": 8}
+    if prof and "shadow" in prof:
+        res["cfg3_shadows_1080p"]["kernels_profiled"] = {k: {"kernel_cycles": round(v.get("kernel_cycles", 0)), "valu_wave_insts": round(v.get("SQ_INSTS_VALU", 0)),
+                                                               "issue_frac_lo": round(v.get("issue_frac_lo", 0), 3), "issue_frac_hi": round(v.get("issue_frac_hi", 0), 3)}
+                                                           for k, v in prof["shadow"].items() if k.startswith("composite") and "true, true" not in k}
     return res
 
 

@@ -29,7 +29,7 @@ extern "C" {
 
 #define NT_MAX_DIM 64            /* run-time-n kernels: n-vectors live in LDS */
 #define NT_MAX_FIXED_DIM 10      /* compile-time-N kernels: 3..10 (reference: setup.py --optimize-dimensions, default 3..8) */
-#define NT_MAX_FIXED_BOX_DIM 16  /* ... BoxScene's also for 11..16 */
+#define NT_MAX_FIXED_BOX_DIM 24  /* ... BoxScene's also for 11..24 */
 #define NT_BATCH_SIZE 4          /* tracern.BATCH_SIZE of the SSE reference build (tracer.hpp:34-38) */
 #define NT_MAX_PIXELSIZE 16      /* bytes per pixel, render.cpp:50 */
 #define NT_MAX_BITSIZE 31        /* integer channel bits, render.cpp:48 */

@@ -1,7 +1,7 @@
 """Build libntracer_hip.so in-tree:  python -m ntracer_amd.build
 
 hipcc cross-compiles gfx950 code objects without a GPU.  The kernels are templates over the dimension; every
-dimension is its own translation unit (csrc/nt_inst_box.hip and csrc/nt_inst_composite.hip with -DNT_INST_N=3..10),
+dimension is its own translation unit (csrc/nt_inst_box.hip with -DNT_INST_N=3..24 and csrc/nt_inst_composite.hip with 3..10),
 compiled in parallel into build/*.o and linked with the host side.  -ffp-contract=off is part of the arithmetic
 contract with the oracle (see csrc/nt_pixel.hpp); -fno-slp-vectorize because packing pairs of independent fp32
 operations into v_pk_* costs more register shuffling than it saves here (measured: 2-4 %)."""
@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libntracer_hip.so")
 DIMS = range(3, 11)
-BOX_ONLY_DIMS = range(11, 17)         # BoxScene kernels alone are also compiled for N = 11..16
+BOX_ONLY_DIMS = range(11, 25)         # BoxScene kernels alone are also compiled for N = 11..24
 HDR = [os.path.join(CSRC, h) for h in ("nt_device.hpp", "nt_pixel.hpp", "nt_box.hpp", "nt_composite.hpp")] + \
       [os.path.join(HERE, "..", "include", "ntracer_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-fno-slp-vectorize", "-Wall",

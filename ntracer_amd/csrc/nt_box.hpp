@@ -452,7 +452,7 @@ __device__ __forceinline__ bool box_pixel(const NtTarget &tg, const PixelRef &pr
 #ifndef NT_BOXROWS
 #define NT_BOXROWS 8
 #endif
-template <int N> struct BoxRows { static constexpr int value = N <= 16 ? NT_BOXROWS : 1; };
+template <int N> struct BoxRows { static constexpr int value = N <= NT_DEV_MAX_FIXED_BOX ? NT_BOXROWS : 1; };
 template <int N, bool PLAIN, int ROWS = BoxRows<N>::value>
 __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg) {
     const int tid = (int)threadIdx.x;

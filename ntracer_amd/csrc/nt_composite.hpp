@@ -1489,8 +1489,12 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
 
 // One wave renders an 8x8 pixel tile (coherent rays -> shared k-d path and broadcast record loads);
 // a 256-thread block covers 16x16 pixels.
+// (experiment switch: -DNT_SHADE_OCC=__attribute__((amdgpu_waves_per_eu(3,3))) holds the kernel to a register budget)
+#ifndef NT_SHADE_OCC
+#define NT_SHADE_OCC
+#endif
 template <int N, bool FEAT, bool STATS>
-__global__ __launch_bounds__(256) void composite_kernel(NtCameraFixed cam, NtCompositeDev sc, NtTarget tg) {
+__global__ __launch_bounds__(256) NT_SHADE_OCC void composite_kernel(NtCameraFixed cam, NtCompositeDev sc, NtTarget tg) {
     extern __shared__ float2 lds_raw[];
     if (nt_aborted(tg)) return;
     const int tid = (int)threadIdx.x;

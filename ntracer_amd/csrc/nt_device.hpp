@@ -6,7 +6,7 @@
 
 #define NT_DEV_MAX_DIM 64
 #define NT_DEV_MAX_FIXED 10
-#define NT_DEV_MAX_FIXED_BOX 16        // BoxScene kernels are also compiled for N = 11..16
+#define NT_DEV_MAX_FIXED_BOX 24        // BoxScene kernels are also compiled for N = 11..24
 #define NT_DEV_BATCH 4
 #define NT_DEV_MAX_REFLECT 16
 

@@ -9,13 +9,21 @@
     int nt_composite_fixed_##N(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg);
 NT_DECLARE_FIXED(3) NT_DECLARE_FIXED(4) NT_DECLARE_FIXED(5) NT_DECLARE_FIXED(6)
 NT_DECLARE_FIXED(7) NT_DECLARE_FIXED(8) NT_DECLARE_FIXED(9) NT_DECLARE_FIXED(10)
-// (BoxScene alone: 11..16)
+// (BoxScene alone: 11..24)
 int nt_box_fixed_14(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 int nt_box_fixed_15(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 int nt_box_fixed_16(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 int nt_box_fixed_11(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 int nt_box_fixed_12(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 int nt_box_fixed_13(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_17(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_18(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_19(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_20(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_21(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_22(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_23(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
+int nt_box_fixed_24(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg);
 
 namespace {
 
@@ -1598,6 +1606,14 @@ int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &t
         case 14: nt_box_fixed_14(li, cam, tg); break;
         case 15: nt_box_fixed_15(li, cam, tg); break;
         case 16: nt_box_fixed_16(li, cam, tg); break;
+        case 17: nt_box_fixed_17(li, cam, tg); break;
+        case 18: nt_box_fixed_18(li, cam, tg); break;
+        case 19: nt_box_fixed_19(li, cam, tg); break;
+        case 20: nt_box_fixed_20(li, cam, tg); break;
+        case 21: nt_box_fixed_21(li, cam, tg); break;
+        case 22: nt_box_fixed_22(li, cam, tg); break;
+        case 23: nt_box_fixed_23(li, cam, tg); break;
+        case 24: nt_box_fixed_24(li, cam, tg); break;
         default: {
             // packed plain RGB of <= 10 bits in one aligned dword: the rows kernel (codes + lean loops), if its n-vectors fit LDS
             const size_t lds_rows = ((size_t)2 * li.n * 256 + (size_t)4 * li.n + 4) * sizeof(float);

@@ -118,7 +118,7 @@ def _stress_cameras(n, rng):
     return cams
 
 
-@pytest.mark.parametrize("n", [3, 4, 6, 8, 10, 11, 13, 16, 20])
+@pytest.mark.parametrize("n", [3, 4, 6, 8, 10, 11, 13, 16, 20, 24, 27])
 def test_box_stress_cameras_bytes_and_floats_equal_oracle(n):
     """The BoxScene kernel sorts rays into clear misses, clear hits and unclear ones, and only the last get the
     reference-ordered evaluation; quantised formats also skip the sqrt and the division away from rounding
@@ -1312,7 +1312,7 @@ def test_shadow_rays_are_counted():
     assert st["shadow_rays"] > 0 and st["rays"] > 96 * 64      # primary + reflection
 
 
-@pytest.mark.parametrize("n", [3, 6, 8, 10])
+@pytest.mark.parametrize("n", [3, 6, 8, 10, 19])
 def test_box_soak_slice(n):
     """A slice of tools/box_soak.py in the suite: 24 random cameras per dimension at full 1920x1080 -- orthonormal frames at
     distances 1.2 .. 12 from the cube, off-axis, every seventh on a diagonal (coordinates equal up to rounding, like the demo's

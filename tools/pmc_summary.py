@@ -47,10 +47,37 @@ def table(d, scale=1.0):
     return res
 
 
+# Issue cost of a wave64 VALU instruction on one SIMD, in cycles (tools/micro/valu_rate2.hip, in-kernel clock): full-rate
+# arithmetic (fma / mul / add / sub, and / xor / ashr / add_u32 / mov) 2, half-rate (max / min / med3, cmp, cndmask, fract, perm, cvt,
+# lshl / bfe / bfi, div_scale / fmas / fixup, readfirstlane) 4, transcendental (rcp / rsq / sqrt) 8.  The counters split the
+# instructions into ADD / MUL / FMA / TRANS f32, INT32, INT64, CVT and a rest (total - these): compares, selects, min / max, moves,
+# bit operations not counted as INT32.  INT32 and the rest are mixtures of 2- and 4-cycle instructions: priced at both.
+PRICE_LO = {"ADD_F32": 2, "MUL_F32": 2, "FMA_F32": 2, "TRANS_F32": 8, "CVT": 4, "INT32": 2, "INT64": 4, "other": 2}
+PRICE_HI = {"ADD_F32": 2, "MUL_F32": 2, "FMA_F32": 2, "TRANS_F32": 8, "CVT": 4, "INT32": 4, "INT64": 8, "other": 4}
+CLASSES = ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "INT64", "CVT")
+
+
+def class_bound(cls, cycles):
+    """cls: {counter: mean per dispatch}; cycles: kernel cycles of the same kernel (another pass) -> classes, issue-limited
+    cycles per SIMD at both pricings and as fractions of the kernel's cycles"""
+    total = cls.get("SQ_INSTS_VALU", 0.0)
+    c = {k: cls.get("SQ_INSTS_VALU_" + k, 0.0) for k in CLASSES}
+    c["other"] = max(0.0, total - sum(c.values()))
+    lo = sum(c[k] * PRICE_LO[k] for k in c) / SIMDS
+    hi = sum(c[k] * PRICE_HI[k] for k in c) / SIMDS
+    e = {"valu_by_class": {k: round(v) for k, v in c.items()}, "issue_cycles_per_simd_lo": lo, "issue_cycles_per_simd_hi": hi,
+         "prices_lo": PRICE_LO, "prices_hi": PRICE_HI}
+    if cycles:
+        e["issue_frac_lo"] = lo / cycles
+        e["issue_frac_hi"] = hi / cycles
+    return e
+
+
 summary = {"tag": tag, "note": "means per dispatch over the profiled run; WRITE_SIZE / FETCH_SIZE are KB in rocprofv3's output and are given in bytes here; "
                                "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B); separate --pmc passes, no tracing"}
-for key, wdir, fdir, sqdir in (("headline", "w", "f", "sq"), ("rgbf32", "f32w", "f32f", "f32sq"), ("config4", "c4w", "c4f", "c4sq")):
-    w, f, sq = table(wdir, 1024.0), table(fdir, 1024.0), table(sqdir)
+for key, wdir, fdir, sqdir, cdir in (("headline", "w", "f", "sq", "cls"), ("rgbf32", "f32w", "f32f", "f32sq", "f32cls"), ("config4", "c4w", "c4f", "c4sq", "c4cls"),
+                                     ("shadow", "shw", "shf", "shsq", "shcls")):
+    w, f, sq, cl = table(wdir, 1024.0), table(fdir, 1024.0), table(sqdir), table(cdir)
     kernels = {}
     for k in sorted(set(w) | set(f) | set(sq)):
         if k.startswith("__amd") or "upload_kernel" in k or "Cijk" in k or k.startswith("at::") or "elementwise" in k:
@@ -76,6 +103,8 @@ for key, wdir, fdir, sqdir in (("headline", "w", "f", "sq"), ("rgbf32", "f32w", 
                 # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU activity over all SIMDs
                 e["valu_busy_frac"] = s.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / SIMDS / cyc
                 e["cycles_per_valu_inst"] = s.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / s["SQ_INSTS_VALU"]
+        if k in cl and "SQ_INSTS_VALU" in cl[k]:
+            e.update(class_bound(cl[k], e.get("kernel_cycles")))
         kernels[k] = e
     summary[key] = kernels
 h = summary["headline"]
@@ -89,20 +118,14 @@ def call_totals(tab, frames, bpp):
         "salu_wave_insts_per_call": sum(v.get("SQ_INSTS_SALU", 0.0) for v in box.values()),
         "valu_active_quad_cycles_per_call": sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in box.values()),
         "kernel_cycles_per_call": sum(v.get("kernel_cycles", 0.0) for v in box.values()),
+        "valu_by_class": {c: sum(v.get("valu_by_class", {}).get(c, 0) for v in box.values()) for c in CLASSES + ("other",)},
+        "issue_cycles_per_simd_lo": sum(v.get("issue_cycles_per_simd_lo", 0.0) for v in box.values()),
+        "issue_cycles_per_simd_hi": sum(v.get("issue_cycles_per_simd_hi", 0.0) for v in box.values()),
         "frames_per_call": frames, "algorithmic_bytes_per_call": 1920 * 1080 * bpp * frames}
 
 
 summary["rgbf32_call"] = call_totals(summary["rgbf32"], 160, 12)
-box = {k: v for k, v in h.items() if k.startswith("box_")}
-summary["headline_call"] = {
-    "kernels": sorted(box),
-    "write_bytes_per_call": sum(v.get("write_bytes", 0.0) for v in box.values()),
-    "fetch_bytes_per_call_corrected": sum(v.get("fetch_bytes_corrected", 0.0) for v in box.values()),
-    "valu_wave_insts_per_call": sum(v.get("SQ_INSTS_VALU", 0.0) for v in box.values()),
-    "salu_wave_insts_per_call": sum(v.get("SQ_INSTS_SALU", 0.0) for v in box.values()),
-    "valu_active_quad_cycles_per_call": sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in box.values()),
-    "kernel_cycles_per_call": sum(v.get("kernel_cycles", 0.0) for v in box.values()),
-    "frames_per_call": 160, "algorithmic_bytes_per_call": 1920 * 1080 * 4 * 160}
+summary["headline_call"] = call_totals(h, 160, 4)
 c4 = {k: v for k, v in summary["config4"].items() if k.startswith("composite_packet")}
 if c4:
     k, v = sorted(c4.items())[0]
@@ -124,7 +147,7 @@ for d, name in (("kt", "bench"), ("b8", "band8")):
                 cur[k] = max(cur.get(k, 0.0), round(sum(v) / len(v), 2))
 json.dump(summary, open(os.path.join(out, tag + "_pmc_summary.json"), "w"), indent=1)
 with open(os.path.join(out, tag + "_sq_counters.txt"), "w") as fh:
-    for key in ("headline", "rgbf32", "config4"):
+    for key in ("headline", "rgbf32", "config4", "shadow"):
         fh.write("== %s\n" % key)
         for k, v in summary[key].items():
             fh.write(k + "\n")
