@@ -273,72 +273,3 @@ def rotating_cameras(nt, cam_distance, frames=160, jitter=True):
         cam.transform(nt.Matrix.rotation(cam.axes[2], a2, incr))
         cam.normalize()
         cam.origin = cam.axes[2] * cam_distance
-
-
-def _write_png(path, rgb):
-    """rgb: (h, w, 3) uint8 -> a PNG file (zlib only)."""
-    import struct
-    import zlib
-    h, w, _ = rgb.shape
-    raw = b"".join(b"\x00" + rgb[y].tobytes() for y in range(h))
-
-    def chunk(tag, data):
-        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
-
-    with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
-                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
-
-
-def main(argv=None):
-    """The non-interactive half of the reference's scripts/polytope.py (:56-77, :588-640): render the rotation of a
-    regular polytope to PNG frames (``-o DIR``) or time it (``--benchmark``).
-
-        python -m ntracer_amd.polytope 5/2 3 3 --benchmark -f 160 -s 1920x1080
-    """
-    import argparse
-    import os
-    import time
-    ap = argparse.ArgumentParser(description="Render a regular polytope given its Schläfli symbol (HIP path).")
-    ap.add_argument("schlafli", metavar="N", nargs="+", help="the Schläfli symbol components, e.g. 5/2 3 3")
-    ap.add_argument("-o", "--output", metavar="DIR", help="write PNG frames to DIR")
-    ap.add_argument("-f", "--frames", type=int, default=160, help="number of frames of the rotation (default 160)")
-    ap.add_argument("-s", "--screen", default="800x600", help="WIDTHxHEIGHT (default 800x600)")
-    ap.add_argument("-a", "--fov", type=float, default=None, help="field of vision in degrees (default 0.8 rad)")
-    ap.add_argument("-d", "--cam-dist", type=float, default=4.0, help="camera distance in circumradii (default 4)")
-    ap.add_argument("--benchmark", action="store_true", help="print the time per frame")
-    a = ap.parse_args(argv)
-    from . import BlockingRenderer, Channel, ImageFormat
-    w, _, h = a.screen.partition("x")
-    w, h = int(w), int(h)
-    if w < 1 or h < 1 or a.frames < 1:
-        ap.error("invalid screen size or frame count")
-    t0 = time.perf_counter()
-    nt, scene, dist = build_scene(a.schlafli, cam_dist=a.cam_dist)
-    if a.fov is not None:
-        if not 0 < a.fov < 180:
-            ap.error("fov must be between 0 and 180 degrees")
-        scene.set_fov(a.fov / 180 * math.pi)
-    print("scene built in %.2f s" % (time.perf_counter() - t0))
-    # RGBX8: 4-byte pixels are written with one coalesced dword per lane (3-byte pixels fall back to byte stores)
-    fmt = ImageFormat(w, h, [Channel(8, 1, 0, 0), Channel(8, 0, 1, 0), Channel(8, 0, 0, 1), Channel(8, 0, 0, 0)])
-    buf = bytearray(fmt.pitch * h)
-    r = BlockingRenderer()
-    if a.output:
-        os.makedirs(a.output, exist_ok=True)
-    total = 0.0
-    for f, cam in enumerate(rotating_cameras(nt, dist, a.frames)):
-        scene.set_camera(cam)
-        t = time.perf_counter()
-        r.render(buf, fmt, scene)
-        total += time.perf_counter() - t
-        if a.output:
-            _write_png(os.path.join(a.output, "frame%05d.png" % f), np.ascontiguousarray(np.frombuffer(bytes(buf), np.uint8).reshape(h, fmt.pitch)[:, :w * 4].reshape(h, w, 4)[:, :, :3]))
-    if a.benchmark:
-        print("rendered %d frame(s) in %g seconds\ntime per frame: %g seconds\nframes per second: %g"
-              % (a.frames, total, total / a.frames, a.frames / total))
-    return 0
-
-
-if __name__ == "__main__":
-    raise SystemExit(main())

@@ -87,29 +87,3 @@ def test_rotating_cameras_match_the_captured_sequence(name, n):
             break
         assert np.abs(np.array(list(cam.origin)) - g["origins"][f]).max() < 2e-5, f
         assert np.abs(np.array([list(cam.axes[i]) for i in range(n)]) - g["axes"][f]).max() < 2e-6, f
-
-
-def test_png_writer_and_cli_argument_checks(tmp_path):
-    import struct
-    import zlib
-    img = (np.arange(5 * 7 * 3) % 251).astype(np.uint8).reshape(5, 7, 3)
-    p = tmp_path / "x.png"
-    polytope._write_png(str(p), img)
-    data = p.read_bytes()
-    assert data[:8] == b"\x89PNG\r\n\x1a\n"
-    w, h, depth, ctype = struct.unpack(">IIBB", data[16:26])
-    assert (w, h, depth, ctype) == (7, 5, 8, 2)
-    idat = data[data.index(b"IDAT") + 4:data.index(b"IEND") - 8]
-    raw = zlib.decompress(idat)
-    rows = np.frombuffer(raw, np.uint8).reshape(5, 1 + 7 * 3)
-    assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(5, 7, 3), img)
-    with pytest.raises(SystemExit):
-        polytope.main(["5", "-s", "0x10"])
-    with pytest.raises(ValueError):
-        polytope.main(["2", "3"])
-
-
-@pytest.mark.gpu
-def test_cli_renders_frames(tmp_path):
-    assert polytope.main(["3", "3", "5", "-f", "2", "-s", "96x64", "-o", str(tmp_path), "--benchmark"]) == 0
-    assert sorted(p.name for p in tmp_path.iterdir()) == ["frame00000.png", "frame00001.png"]

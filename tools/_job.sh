@@ -1,3 +1,1 @@
-python -m pytest tests -m gpu -x -q > gpurun_out/r3_t5.log 2>&1; tail -4 gpurun_out/r3_t5.log
-for n in 16 17 20 24; do python tools/boxn_time.py $n 64 5 2>&1 | grep Box; done
-for n in 17 24; do NTRACER_FORCE_VAR=1 python tools/boxn_time.py $n 64 3 2>&1 | grep Box; done
+python tools/il_ab.py --var NTRACER_BOX_R64 --values 0,1 --cases band8 --rounds 6 --steps 20
