@@ -453,8 +453,12 @@ __device__ __forceinline__ bool leaf_occludes(const NtCompositeDev &sc, int star
 
 // _occludes (tracer.hpp:1258-1307), including `if(t < ldistance) return false;` at :1298 -- the far
 // child is skipped whenever the split lies nearer than the light (reference quirk, reproduced).
+// (experiment switch: -DNT_OCCL_ATTR=__forceinline__ puts the shadow walk into the shading loop instead of behind a call)
+#ifndef NT_OCCL_ATTR
+#define NT_OCCL_ATTR __noinline__
+#endif
 template <int N, bool STATS>
-__device__ __noinline__ bool trace_occluded(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
+__device__ NT_OCCL_ATTR bool trace_occluded(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
                                             float ldistance, int skip_item, int skip_lane, Stats &st) {
     setup_ray_table<N>(w, lane, o, d);
     int node = sc.root;
@@ -1846,8 +1850,16 @@ __device__ __forceinline__ bool wm_claim(int *wm, int lane, int item, bool activ
 // neighbouring rays walk the same leaves, so the four waves share what their scalar loads bring into the CU's
 // scalar cache (blocks of unrelated tiles ran ~12 % slower).  Quads are dispatched through a host table: quad
 // rows nearest the image centre first (they hold the long walks), row-major within a row.
+// (experiment switches: -DNT_PACKET_WAVES4=7 -DNT_PACKET_ATTR=__attribute__((amdgpu_num_sgpr(96))): waves per SIMD asked of the lean
+// kernel up to four dimensions, and a scalar-register budget that admits them -- 106 SGPRs admit six 256-thread blocks a CU)
+#ifndef NT_PACKET_WAVES4
+#define NT_PACKET_WAVES4 6
+#endif
+#ifndef NT_PACKET_ATTR
+#define NT_PACKET_ATTR
+#endif
 template <int N, int DEPTH, bool FEAT, bool SCAL>
-__global__ __launch_bounds__(256, FEAT ? 1 : ((N <= 4 && !SCAL) ? 6 : (N <= 7 ? 5 : 4))) void composite_packet(NtCompositeDev sc, NtTarget tg, PacketArgs pa) {
+__global__ __launch_bounds__(256, FEAT ? 1 : ((N <= 4 && !SCAL) ? NT_PACKET_WAVES4 : (N <= 7 ? 5 : 4))) NT_PACKET_ATTR void composite_packet(NtCompositeDev sc, NtTarget tg, PacketArgs pa) {
     extern __shared__ float2 lds_raw[];
     if (nt_aborted(tg)) return;                           // (four independent waves: no barrier in this kernel)
     const int lane = (int)threadIdx.x & 63;
