@@ -138,7 +138,10 @@ typedef struct {
                                     tests).  1: walk exactly the cells the reference walks
                                     (src/tracer.hpp:1179-1243).  NTRACER_STRICT_REFERENCE=1 in the environment forces 1,
                                     also for nt_colors_at / nt_calculate_color, which take no options. */
-    int32_t collect_stats;       /* 1: count rays/nodes/tests with device atomics (slower) */
+    int32_t collect_stats;       /* 1: count rays/nodes/tests with device atomics (slower).  Never changes the pixels: scenes whose
+                                    frames come from kernels without counters (Solids with the reference's normal handling) are
+                                    drawn as always and counted by a launch of their own (the counters then describe the
+                                    clean-normal traversal); scenes with transparent materials, and n > 10: NT_E_UNSUPPORTED */
     int32_t reserved;
     /* Abort for the device entry points (nt_render_device / nt_render_frames_device), which only enqueue: NULL, or a dword
        the DEVICE can read while the kernels run -- best in device memory, raised by a 4-byte copy on another stream
