@@ -222,6 +222,18 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
                             const float *origins, const float *axes, const nt_image_format *fmt,
                             const nt_render_opts *opts, void *hip_stream);
 
+/* A camera path resident in device memory: the cameras of a sequence (the RotatingCamera loop of scripts/polytope.py:522-556
+   has 160) packed and uploaded ONCE; nt_render_table_device then renders frames [first, first + count) of it exactly like
+   nt_render_frames_device, but with nothing to pack or upload per call -- one kernel launch instead of two, which is what a
+   render loop over a fixed path, and a rank's small share of a tiled frame, spend a tenth of their time on.
+   The table belongs to the scene's dimension and to one device; it may be used by any scene of that dimension. */
+typedef struct nt_camera_table nt_camera_table_t;
+nt_camera_table_t *nt_camera_table_create(int dimension, int nframes, const float *origins, const float *axes, int device);
+void nt_camera_table_destroy(nt_camera_table_t *t);
+int nt_camera_table_frames(const nt_camera_table_t *t);
+int nt_render_table_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, const nt_camera_table_t *table, int first, int count,
+                           const nt_image_format *fmt, const nt_render_opts *opts, void *hip_stream);
+
 /* Scene.calculate_color(x,y,width,height) (render.cpp:586-614): unpacked fp32 colour of one pixel,
    computed by the same device code as nt_render. */
 int nt_calculate_color(nt_scene_t *s, int x, int y, int width, int height, float rgb[3]);

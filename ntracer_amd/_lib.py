@@ -114,6 +114,11 @@ SYMBOLS = [
                                    C.POINTER(NtRenderOpts), C.c_void_p]),
     ("nt_render_frames_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, f32p, f32p,
                                           C.POINTER(NtImageFormat), C.POINTER(NtRenderOpts), C.c_void_p]),
+    ("nt_camera_table_create", C.c_void_p, [C.c_int, C.c_int, f32p, f32p, C.c_int]),
+    ("nt_camera_table_destroy", None, [C.c_void_p]),
+    ("nt_camera_table_frames", C.c_int, [C.c_void_p]),
+    ("nt_render_table_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int,
+                                         C.POINTER(NtImageFormat), C.POINTER(NtRenderOpts), C.c_void_p]),
     ("nt_calculate_color", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
     ("nt_colors_at", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, i32p, f32p, C.c_int]),
     ("nt_scene_last_stats", C.c_int, [C.c_void_p, C.POINTER(NtStats)]),

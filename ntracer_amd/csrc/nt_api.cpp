@@ -1248,8 +1248,13 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
             return fail(NT_E_DEVICE, "%s", nt_launch_error());
         }
     }
-    HIP_TRY(hipEventRecord(st->done, (hipStream_t)hip_stream));
-    st->in_flight = true;
+    {
+        const char *ese = getenv("NTRACER_STAGE_EVENT");     // (experiment: 0 = no event behind the upload; unsafe beyond 8 calls in flight)
+        if (!(ese && atoi(ese) == 0)) {
+            HIP_TRY(hipEventRecord(st->done, (hipStream_t)hip_stream));
+            st->in_flight = true;
+        }
+    }
     const bool stats = opts && opts->collect_stats;
     if (int r = prepare_stats(ds, (hipStream_t)hip_stream, stats)) return r;
     if (stats) { s->have_stats = false; s->stats_device = dev; }
@@ -1260,6 +1265,87 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     job.frame_stride = frame_stride;
     job.nframes = nframes;
     job.cam_buf = (const float *)ds->cams.p;
+    job.stream = (hipStream_t)hip_stream;
+    job.stats = stats;
+    job.strict = opts && opts->strict_reference;
+    job.abort_word = opts ? (const int *)opts->abort_device : nullptr;
+    job.row_begin = 0;
+    job.row_count = b.owned_rows;
+    return enqueue(s, ds, job);
+}
+
+struct nt_camera_table {
+    int n = 0, nframes = 0, device = -1;
+    float *dev = nullptr;                // [nframes][4][n] camera rows, then [nframes][4] dot products (NtCamera::buf)
+};
+
+nt_camera_table_t *nt_camera_table_create(int dimension, int nframes, const float *origins, const float *axes, int device) {
+    if (dimension < 3 || dimension > NT_MAX_DIM || nframes < 1 || nframes > 65535 || !origins || !axes) {
+        fail(NT_E_INVALID, "invalid camera table arguments");
+        return nullptr;
+    }
+    int dev;
+    if (pick_device(nullptr, device, dev)) return nullptr;
+    const int n = dimension;
+    const size_t cam_floats = (size_t)nframes * 4 * n + (size_t)nframes * 4;
+    std::vector<float> packed(cam_floats);
+    for (int f = 0; f < nframes; ++f) {
+        pack_camera(n, origins + (size_t)f * n, axes + (size_t)f * n * n, packed.data() + (size_t)f * 4 * n);
+        camera_dots(n, origins + (size_t)f * n, axes + (size_t)f * n * n, packed.data() + (size_t)nframes * 4 * n + (size_t)f * 4);
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, cam_floats * sizeof(float)) != hipSuccess) { fail(NT_E_NOMEM, "hipMalloc failed for the camera table"); return nullptr; }
+    if (hipMemcpy(p, packed.data(), cam_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(p);
+        fail(NT_E_DEVICE, "camera table upload failed");
+        return nullptr;
+    }
+    nt_camera_table *t = new (std::nothrow) nt_camera_table();
+    if (!t) { (void)hipFree(p); fail(NT_E_NOMEM, "out of memory"); return nullptr; }
+    t->n = n; t->nframes = nframes; t->device = dev; t->dev = (float *)p;
+    return t;
+}
+
+void nt_camera_table_destroy(nt_camera_table_t *t) {
+    if (!t) return;
+    if (t->dev && hipSetDevice(t->device) == hipSuccess) { (void)hipDeviceSynchronize(); (void)hipFree(t->dev); }
+    delete t;
+}
+
+int nt_camera_table_frames(const nt_camera_table_t *t) { return t ? t->nframes : fail(NT_E_INVALID, "table is NULL"); }
+
+int nt_render_table_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, const nt_camera_table_t *table, int first, int count,
+                           const nt_image_format *fmt, const nt_render_opts *opts, void *hip_stream) {
+    if (!s || !dest_dev || !table) return fail(NT_E_INVALID, "NULL argument");
+    if (table->n != s->n) return fail(NT_E_INVALID, "the camera table is for %d dimensions, the scene has %d", table->n, s->n);
+    // (the dot products of all the table's frames lie behind its last camera, where the kernels look for them by the launch's
+    // frame count: a launch covers the whole table)
+    if (first != 0 || count != table->nframes) return fail(NT_E_UNSUPPORTED, "a launch renders the whole table: first must be 0 and count its frame count");
+    Format f;
+    if (int r = parse_format(fmt, f)) return r;
+    Bands b;
+    if (int r = parse_bands(opts, f.height, b)) return r;
+    if (frame_stride < required_len(f, b)) return fail(NT_E_INVALID, "frame_stride is smaller than one frame");
+    if (int r = check_renderable(s)) return r;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->busy) return fail(NT_E_BUSY, "the renderer is already running");
+    int dev;
+    if (int r = pick_device(opts, -1, dev)) return r;
+    if (dev != table->device) return fail(NT_E_INVALID, "the camera table lives on device %d, the render is for device %d", table->device, dev);
+    DeviceState *ds;
+    if (int r = device_state(s, dev, ds)) return r;
+    if (int r = upload_scene(s, ds)) return r;
+    if (int r = use_stream(ds, (hipStream_t)hip_stream)) return r;
+    const bool stats = opts && opts->collect_stats;
+    if (int r = prepare_stats(ds, (hipStream_t)hip_stream, stats)) return r;
+    if (stats) { s->have_stats = false; s->stats_device = dev; }
+    FrameJob job{};
+    job.fmt = &f;
+    job.bands = b;
+    job.dest_dev = dest_dev;
+    job.frame_stride = frame_stride;
+    job.nframes = count;
+    job.cam_buf = table->dev;
     job.stream = (hipStream_t)hip_stream;
     job.stats = stats;
     job.strict = opts && opts->strict_reference;

@@ -419,6 +419,44 @@ def _opts(device=-1, band_rank=0, band_world=1, compact=False, collect_stats=Fal
     return o
 
 
+class CameraTable(object):
+    """A camera path resident in device memory (``nt_camera_table_create``): the cameras of a sequence -- e.g. the 160 of
+    the reference's RotatingCamera loop, scripts/polytope.py:522-556 -- packed and uploaded once.  ``render(scene, dest,
+    format)`` then renders one frame per camera into ``dest`` (a torch HIP tensor of at least ``frames * frame_bytes``
+    bytes; the launch is enqueued on torch's current stream) with nothing to pack or upload per call."""
+
+    def __init__(self, dimension, origins, axes, device=-1):
+        import numpy as np
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, dimension)
+        a = np.ascontiguousarray(axes, np.float32).reshape(len(o), dimension, dimension)
+        self.dimension = int(dimension)
+        self.frames = len(o)
+        self._h = _lib.lib().nt_camera_table_create(self.dimension, self.frames, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), int(device))
+        if not self._h:
+            raise RuntimeError(_lib.last_error())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().nt_camera_table_destroy(h)
+            except Exception:
+                pass
+
+    def render(self, scene, dest, format, frame_bytes=None, band_rank=0, band_world=1, compact=False, band_rows=0, strict_reference=None):
+        dev = _device_pointer(dest)
+        if dev is None:
+            raise TypeError("dest must be a torch HIP tensor")
+        ptr, nbytes, index, stream = dev
+        fmt = format._as_struct()
+        opts = _opts(index, band_rank, band_world, compact, False, band_rows=band_rows, strict_reference=strict_reference)
+        if frame_bytes is None:
+            frame_bytes = nbytes // self.frames
+        _lib.check(_lib.lib().nt_render_table_device(scene._handle, C.c_void_p(ptr), frame_bytes, self._h, 0, self.frames, C.byref(fmt),
+                                                     C.byref(opts), C.c_void_p(stream)))
+        return True
+
+
 class BlockingRenderer(object):
     """render.BlockingRenderer([threads=-1]) -- render.cpp:769-923.
 

@@ -1355,6 +1355,58 @@ def test_box_soak_slice(n):
             assert np.array_equal(got[f], ref), (n, f, fmt.bytes_per_pixel, int((got[f] != ref).sum()))
 
 
+def test_camera_table_renders_the_same_frames():
+    """nt_camera_table_create / nt_render_table_device (cameras of a path resident in device memory, one launch a call) against
+    nt_render_frames_device (cameras packed and uploaded per call): the same bytes, for BoxScene -- whole frames and one
+    rank's bands -- and for the 120-cell's packet kernel; and the refusals (wrong dimension, part of a table)."""
+    import torch
+    from ntracer_amd.render import CameraTable
+    g = fx.load("box_n6_1920x1080")
+    F = 12
+    o = np.ascontiguousarray(g["origins"][10:10 + F], np.float32)
+    a = np.ascontiguousarray(g["axes"][10:10 + F], np.float32)
+    sc = tracern.BoxScene(6)
+    fmt = fmt_of(1920, 1080, fx.RGBX8)
+    fst = fmt._as_struct()
+    tab = CameraTable(6, o, a)
+    assert tab.frames == F
+    st = torch.cuda.current_stream().cuda_stream
+    for world, rank, brows in ((1, 0, 32), (8, 3, 8)):
+        opts = _lib.NtRenderOpts()
+        opts.device = -1
+        opts.band_rank, opts.band_world, opts.band_rows, opts.compact = rank, world, brows, 1
+        rows = len(ntd.owned_rows(1080, rank, world, brows))
+        a_fb = torch.zeros((F, rows * fmt.pitch), dtype=torch.uint8, device="cuda")
+        b_fb = torch.zeros_like(a_fb)
+        _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(a_fb.data_ptr()), rows * fmt.pitch, F, o.ctypes.data_as(_lib.f32p),
+                                                      a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts), C.c_void_p(st)))
+        assert tab.render(sc, b_fb, fmt, band_rank=rank, band_world=world, compact=True, band_rows=brows)
+        torch.cuda.synchronize()
+        assert torch.equal(a_fb, b_fb), (world, rank)
+    ref = ob.OracleScene(6, o[5], a[5]).render(1920, 1080, fx.RGBX8, threads=8)
+    full = torch.zeros((F, 1080 * fmt.pitch), dtype=torch.uint8, device="cuda")
+    tab.render(sc, full, fmt)
+    torch.cuda.synchronize()
+    assert np.array_equal(full[5].cpu().numpy().reshape(1080, fmt.pitch), ref)
+    with pytest.raises(ValueError, match="dimensions"):
+        tab.render(tracern.BoxScene(5), full, fmt)
+    with pytest.raises(NotImplementedError):
+        _lib.check(_lib.lib().nt_render_table_device(sc._handle, C.c_void_p(full.data_ptr()), 1080 * fmt.pitch, tab._h, 2, 4, C.byref(fst), None, C.c_void_p(st)))
+    g4 = fx.load("cell120_n4")
+    sc4 = tracern.CompositeScene.from_flat(4, fx.flat_of(g4))
+    o4 = np.ascontiguousarray(g4["origins"][[0, 40, 93]], np.float32)
+    a4 = np.ascontiguousarray(g4["axes"][[0, 40, 93]], np.float32)
+    fmt4 = fmt_of(640, 360, fx.RGBX8)
+    fst4 = fmt4._as_struct()
+    x = torch.zeros((3, 360 * fmt4.pitch), dtype=torch.uint8, device="cuda")
+    y = torch.zeros_like(x)
+    _lib.check(_lib.lib().nt_render_frames_device(sc4._handle, C.c_void_p(x.data_ptr()), 360 * fmt4.pitch, 3, o4.ctypes.data_as(_lib.f32p),
+                                                  a4.ctypes.data_as(_lib.f32p), C.byref(fst4), None, C.c_void_p(st)))
+    CameraTable(4, o4, a4).render(sc4, y, fmt4)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+
+
 def test_box_kernel_paths_alternate_on_one_scene(monkeypatch):
     """The packed-RGB formats normally take the fused tile kernel; NTRACER_BOX_PATH=0 selects the older cull -> box -> redo
     kernels, which share the scene's scratch buffer with it (the fused path keeps a bitmap there that must be all zero between
