@@ -1852,6 +1852,13 @@ __device__ __forceinline__ bool wm_claim(int *wm, int lane, int item, bool activ
 // rows nearest the image centre first (they hold the long walks), row-major within a row.
 // (experiment switches: -DNT_PACKET_WAVES4=7 -DNT_PACKET_ATTR=__attribute__((amdgpu_num_sgpr(96))): waves per SIMD asked of the lean
 // kernel up to four dimensions, and a scalar-register budget that admits them -- 106 SGPRs admit six 256-thread blocks a CU)
+// the packet walk looks at the abort word on every stack pop whose node id has these bits clear: 0 = every pop.  (Measured,
+// tools/abort_probe.py, the 120-cell walked strictly at 4096 x 4096, a 10.3 ms frame: with mask 63 a raised flag took 2.4-5.9 ms
+// to bring nt_render back -- the long walks through the middle of the scene pop few such nodes -- with 0 it takes 0.4-1.6 ms,
+// and the frame, aborted or not, takes the same time: the look is a load nothing else waits for but the branch on it.)
+#ifndef NT_ABORT_POLL_MASK
+#define NT_ABORT_POLL_MASK 0
+#endif
 #ifndef NT_PACKET_WAVES4
 #define NT_PACKET_WAVES4 6
 #endif
@@ -2078,9 +2085,9 @@ __global__ __launch_bounds__(256, FEAT ? 1 : ((N <= 4 && !SCAL) ? NT_PACKET_WAVE
         if (sp == 0) break;
         --sp;
         const int far = __builtin_amdgcn_readfirstlane(ustack[sp * 8 + 0]);
-        // (abort: a look at the word on one pop in 64 -- by the node id, which costs no counter -- so that a wave on one of
-        // the long walks through the middle of a scene does not hold an aborted frame for milliseconds)
-        if (tg.abort_word != nullptr && (far & 63) == 0 && nt_aborted(tg)) return;
+        // (abort: a look at the word on every pop -- NT_ABORT_POLL_MASK -- so that a wave on one of the long walks through the
+        // middle of a scene does not hold an aborted frame for milliseconds)
+        if (tg.abort_word != nullptr && (far & NT_ABORT_POLL_MASK) == 0 && nt_aborted(tg)) return;
         const unsigned long long m = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 8 + 2]) << 32) |
                                      (unsigned int)__builtin_amdgcn_readfirstlane(ustack[sp * 8 + 1]);
         const bool was_both = ((bothbits >> sp) & 1u) != 0u;

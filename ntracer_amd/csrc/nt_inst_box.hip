@@ -1,5 +1,20 @@
 // nt_inst_box.hip -- instantiates the BoxScene kernels of nt_box.hpp.  The build compiles this file once per dimension
 // (-DNT_INST_N=3 .. 24, in parallel); without the macro every dimension is instantiated here.
+// Dimensions whose tile kernel sits a few registers above an occupancy step are held to the step (`amdgpu_waves_per_eu` takes no
+// template arguments, hence per translation unit; -DNT_TILE_OCC=... overrides).  Measured (tools/il_ab.py, tools/boxn_time.py,
+// settled clocks): n = 10, 100 VGPRs -> 95, five waves a SIMD instead of four: sixteen 4096 x 4096 frames 337 -> 309 us (-8 %);
+// n = 15, 132 -> 128, four instead of three: 414 -> 439 Grays/s; n = 21..24, 178..199 -> 168 (a few dwords a lane spilled),
+// three instead of two: 204 -> 270, 196 -> 260, 193 -> 249, 192 -> 223 Grays/s.  No gain, not taken: n = 6 at seven waves
+// (72 VGPRs, three dwords spilled: 353.9 vs 353.6 us on the headline), n = 7, 8 at six, n = 16 at four.
+#if defined(NT_INST_N) && !defined(NT_TILE_OCC)
+#if NT_INST_N == 10
+#define NT_TILE_OCC __attribute__((amdgpu_waves_per_eu(5, 5)))
+#elif NT_INST_N == 15
+#define NT_TILE_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#elif NT_INST_N >= 21 && NT_INST_N <= 24
+#define NT_TILE_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
+#endif
 #include "nt_box.hpp"
 
 #define NT_DEFINE_BOX(N) \
