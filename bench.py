@@ -284,9 +284,14 @@ def main():
             cfg5 = config5(torch, dist, ntracer_amd, tracern, _lib, ntd, rank, world, local_rank)
         except Exception as e:           # never hide the headline
             cfg5 = {"error": repr(e)[:300]}
+    # the last collective is behind us: every rank leaves the process group together, here -- rank 0 goes on alone with the CPU
+    # baseline and the line (a rank that tears its communicator down long after its peers have exited is how jobs hang)
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        dist = None
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
 
     # correctness guard inside the bench: the last rendered frame's checksum equals a fresh single render
