@@ -272,7 +272,10 @@ __device__ __forceinline__ void setup_ray_table(const WaveLds &w, int lane, cons
 
 // One leaf (kd_leaf<Store,true>::intersects, tracer.hpp:977-1086) for all-opaque scenes: every
 // hit tightens the cutoff, so the two-loop structure collapses to "keep the nearest, first wins".
-template <int N, bool FEAT, bool STATS>
+// SCALP: leaves may hold unbatched triangles and solids (NtCompositeDev::has_scalar_prims).  Scenes made of batches alone --
+// every polytope of the reference's scripts -- take the instantiations without: no call to solid_intersects in the leaf
+// loops, and with it a good part of the shading kernel's registers (214 VGPRs with, two waves a SIMD).
+template <int N, bool FEAT, bool STATS, bool SCALP = FEAT>
 __device__ __forceinline__ bool leaf_closest(const NtCompositeDev &sc, const WaveLds &w, int lane, int start, int count,
                                              const float (&o)[N], const float (&d)[N], int skip_item, int skip_lane, Hit &hit, Stats &st) {
     bool improved = false;
@@ -295,7 +298,7 @@ __device__ __forceinline__ bool leaf_closest(const NtCompositeDev &sc, const Wav
             }
             if (STATS) st.simplex_tests += NT_DEV_BATCH;
             if (r >= 0) { hit.dist = min_t; hit.item = item; hit.lane = r; improved = true; }
-        } else if (FEAT && item != skip_item) {
+        } else if (SCALP && item != skip_item) {
             float t;
             if (kind == 1) {
                 SimplexRec<N> s;
@@ -337,7 +340,7 @@ __device__ __forceinline__ float branch_t(const WaveLds &w, int lane, const NtNo
     return (nd.split - oi.x) * oi.y;
 }
 
-template <int N, bool FEAT, bool STATS>
+template <int N, bool FEAT, bool STATS, bool SCALP = FEAT>
 __device__ __noinline__ bool trace_closest(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
                                               float t_near, float t_far_root, int skip_item, int skip_lane, Hit &hit, Stats &st) {
     hit.dist = FLT_MAX;
@@ -355,7 +358,7 @@ __device__ __noinline__ bool trace_closest(const NtCompositeDev &sc, const WaveL
             const NtNode nd = sc.nodes[node];
             if (nd.axis < 0) {
                 if (STATS) st.leaves += 1;
-                if (leaf_closest<N, FEAT, STATS>(sc, w, lane, nd.left, nd.right, o, d, skip_item, skip_lane, hit, st)) dirty = sp;
+                if (leaf_closest<N, FEAT, STATS, SCALP>(sc, w, lane, nd.left, nd.right, o, d, skip_item, skip_lane, hit, st)) dirty = sp;
                 node = -1;
                 break;
             }
@@ -413,7 +416,7 @@ __device__ __noinline__ bool trace_closest(const NtCompositeDev &sc, const WaveL
 }
 
 // kd_leaf::occludes (tracer.hpp:1088-1124), all-opaque scenes
-template <int N, bool STATS>
+template <int N, bool STATS, bool SCALP = true>
 __device__ __forceinline__ bool leaf_occludes(const NtCompositeDev &sc, int start, int count, const float (&o)[N], const float (&d)[N],
                                               float ldistance, int skip_item, int skip_lane, Stats &st) {
     for (int i = 0; i < count; ++i) {
@@ -433,7 +436,7 @@ __device__ __forceinline__ bool leaf_occludes(const NtCompositeDev &sc, int star
             }
             if (STATS) st.simplex_tests += NT_DEV_BATCH;
             if (any) return true;
-        } else if (item != skip_item) {
+        } else if (SCALP && item != skip_item) {
             float t;
             if (kind == 1) {
                 SimplexRec<N> s;
@@ -457,7 +460,7 @@ __device__ __forceinline__ bool leaf_occludes(const NtCompositeDev &sc, int star
 #ifndef NT_OCCL_ATTR
 #define NT_OCCL_ATTR __noinline__
 #endif
-template <int N, bool STATS>
+template <int N, bool STATS, bool SCALP = true>
 __device__ NT_OCCL_ATTR bool trace_occluded(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
                                             float ldistance, int skip_item, int skip_lane, Stats &st) {
     setup_ray_table<N>(w, lane, o, d);
@@ -472,7 +475,7 @@ __device__ NT_OCCL_ATTR bool trace_occluded(const NtCompositeDev &sc, const Wave
             const NtNode nd = sc.nodes[node];
             if (nd.axis < 0) {
                 if (STATS) st.leaves += 1;
-                if (leaf_occludes<N, STATS>(sc, nd.left, nd.right, o, d, ldistance, skip_item, skip_lane, st)) return true;
+                if (leaf_occludes<N, STATS, SCALP>(sc, nd.left, nd.right, o, d, ldistance, skip_item, skip_lane, st)) return true;
                 node = -1;
                 break;
             }
@@ -571,7 +574,7 @@ __device__ __forceinline__ const float *material_of(const NtCompositeDev &sc, in
 }
 
 // normal ray of the recorded hit (what the reference stored in o_hit.normal)
-template <int N, bool FEAT>
+template <int N, bool FEAT>          // (FEAT here: hits may be solids)
 __device__ __forceinline__ void hit_normal(const NtCompositeDev &sc, const Hit &hit, const float (&o)[N], const float (&d)[N],
                                            float (&no)[N], float (&nd)[N]) {
     const int kind = hit.item & 3, idx = hit.item >> 2;
@@ -677,7 +680,7 @@ __device__ __forceinline__ Color3 surface_color_lean(const NtCompositeDev &sc, c
 
 // `primary`: when not null, the closest hit of the depth-0 ray has already been found (by the packet walk) and
 // is taken from there instead of being traced here.
-template <int N, bool FEAT, bool STATS>
+template <int N, bool FEAT, bool STATS, bool SCALP = FEAT>
 __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, const WaveLds &w, int lane, float (&o)[N], float (&d)[N], Stats &st,
                                                   const Hit *primary = nullptr) {
     Level levels[FEAT ? NT_DEV_MAX_REFLECT : 1];
@@ -701,7 +704,7 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
             if (dist >= 0.0f) {
                 if (STATS && depth == 0) st.aabb_enter += 1;
                 setup_ray_table<N>(w, lane, o, d);
-                found = trace_closest<N, FEAT, STATS>(sc, w, lane, o, d, dist, FLT_MAX, skip_item, skip_lane, hit, st);
+                found = trace_closest<N, FEAT, STATS, SCALP>(sc, w, lane, o, d, dist, FLT_MAX, skip_item, skip_lane, hit, st);
             }
         }
         if (!found) {
@@ -712,7 +715,7 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
 
         // ---- base_color (tracer.hpp:1768-1854) ----
         float no[N], nd[N];
-        hit_normal<N, FEAT>(sc, hit, o, d, no, nd);
+        hit_normal<N, SCALP>(sc, hit, o, d, no, nd);
         const float *m = material_of(sc, hit.item, hit.lane);
         Color3 light = c3(0.0f, 0.0f, 0.0f), specular = c3(0.0f, 0.0f, 0.0f);
         float spec_a = 0.0f;
@@ -729,10 +732,10 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
                 for (int k = 0; k < N; ++k) lv[k] = lv[k] / ldist;
                 const float sine = dotN<N>(nd, lv);
                 if (sine > 0.0f) {
-                    const float strength = (float)(1.0 / pow((double)ldist, (double)(N - 1)));
+                    const float strength = nt_falloff(ldist, N - 1);
                     if (sc.shadows) {
                         if (fmaxf(plc.r, fmaxf(plc.g, plc.b)) * strength * sine > NT_LIGHT_THRESHOLD) {
-                            if (!trace_occluded<N, STATS>(sc, w, lane, no, lv, ldist, hit.item, hit.lane, st)) {
+                            if (!trace_occluded<N, STATS, SCALP>(sc, w, lane, no, lv, ldist, hit.item, hit.lane, st)) {
                                 const Color3 filtered = cscale(plc, strength);
                                 light = cadd(light, cscale(filtered, sine));
                                 if (m[8] != 0.0f) append_specular<N>(specular, spec_a, m, filtered, d, nd, lv);
@@ -752,7 +755,7 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
                 const float sine = -dotN<N>(nd, gdir);
                 if (sine > 0.0f) {
                     if (sc.shadows) {
-                        if (!trace_occluded<N, STATS>(sc, w, lane, no, neg, FLT_MAX, hit.item, hit.lane, st)) {
+                        if (!trace_occluded<N, STATS, SCALP>(sc, w, lane, no, neg, FLT_MAX, hit.item, hit.lane, st)) {
                             light = cadd(light, cscale(glc, sine));
                             if (m[8] != 0.0f) append_specular<N>(specular, spec_a, m, glc, d, nd, neg);
                         }
@@ -1368,7 +1371,7 @@ __device__ __noinline__ Color3 composite_color_t(const NtCompositeDev &sc, const
                 for (int k = 0; k < N; ++k) lv[k] = lv[k] / ldist;
                 const float sine = dotN<N>(nd, lv);
                 if (sine > 0.0f) {
-                    const float strength = (float)(1.0 / pow((double)ldist, (double)(N - 1)));
+                    const float strength = nt_falloff(ldist, N - 1);
                     if (sc.shadows) {
                         if (fmaxf(plc.r, fmaxf(plc.g, plc.b)) * strength * sine > NT_LIGHT_THRESHOLD) {
                             Color3 filtered = plc;
@@ -1497,7 +1500,7 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
 #ifndef NT_SHADE_OCC
 #define NT_SHADE_OCC
 #endif
-template <int N, bool FEAT, bool STATS>
+template <int N, bool FEAT, bool STATS, bool SCALP = FEAT>
 __global__ __launch_bounds__(256) NT_SHADE_OCC void composite_kernel(NtCameraFixed cam, NtCompositeDev sc, NtTarget tg) {
     extern __shared__ float2 lds_raw[];
     if (nt_aborted(tg)) return;
@@ -1527,9 +1530,9 @@ __global__ __launch_bounds__(256) NT_SHADE_OCC void composite_kernel(NtCameraFix
             hit.item = __float_as_int(h.y);
             hit.lane = __float_as_int(h.z);
             emit = hit.item >= 0;
-            if (emit) c = composite_color<N, FEAT, STATS>(sc, w, lane, org, dir, st, &hit);
+            if (emit) c = composite_color<N, FEAT, STATS, SCALP>(sc, w, lane, org, dir, st, &hit);
         } else {
-            c = composite_color<N, FEAT, STATS>(sc, w, lane, org, dir, st);
+            c = composite_color<N, FEAT, STATS, SCALP>(sc, w, lane, org, dir, st);
         }
         if (emit) emit_pixel(tg, pr, c.r, c.g, c.b);
     }
@@ -2254,7 +2257,9 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
                 c2.buf = li.persist_cams + (size_t)f0 * 4 * N;
                 dim3 g2;
                 grid_for(t2, 16, 16, cnt, g2);
-                hipLaunchKernelGGL((composite_kernel<N, true, false>), g2, dim3(256), lds, s, c2, sc, t2);
+                // (scenes made of batches alone: the instantiation without unbatched triangles and solids in its leaf loops)
+                if (sc.has_scalar_prims) hipLaunchKernelGGL((composite_kernel<N, true, false>), g2, dim3(256), lds, s, c2, sc, t2);
+                else hipLaunchKernelGGL((composite_kernel<N, true, false, false>), g2, dim3(256), lds, s, c2, sc, t2);
             }
         }
         return 0;
@@ -2279,6 +2284,7 @@ int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const Nt
         return 0;
     }
     if (sc.stats) hipLaunchKernelGGL((composite_kernel<N, true, true>), grid, dim3(256), lds, s, cf, sc, tg);
+    else if (feat && !sc.has_scalar_prims) hipLaunchKernelGGL((composite_kernel<N, true, false, false>), grid, dim3(256), lds, s, cf, sc, tg);
     else if (feat) hipLaunchKernelGGL((composite_kernel<N, true, false>), grid, dim3(256), lds, s, cf, sc, tg);
     else hipLaunchKernelGGL((composite_kernel<N, false, false>), grid, dim3(256), lds, s, cf, sc, tg);
     return 0;

@@ -27,6 +27,18 @@ __device__ __forceinline__ bool nt_aborted(const NtTarget &tg) {
     return tg.abort_word != nullptr && __hip_atomic_load(tg.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
 }
 
+// point_light::strength (tracer.hpp:1686-1688): 1 / std::pow(distance, dimension - 1) -- float and int arguments, so the
+// reference's pow is the double one.  The exponent is a small positive integer: x^k by k - 1 multiplications in double agrees
+// with the library's pow to an ulp or two of a DOUBLE, i.e. gives the same float after the final rounding (all but ~1e-8 of
+// the time), and needs a handful of registers where the library's f64 pow -- logarithm, exponential, special cases -- needs
+// dozens of register pairs: it alone set the shading kernels' register allocation.
+__device__ __forceinline__ float nt_falloff(float distance, int k) {
+    const double x = (double)distance;
+    double p = x;
+    for (int i = 1; i < k; ++i) p *= x;
+    return (float)(1.0 / p);
+}
+
 // --------------------------------------------------------------------------------------
 // pixel packing: render.cpp:419-462
 // --------------------------------------------------------------------------------------

@@ -809,7 +809,7 @@ __device__ __noinline__ Color3 composite_color_var(const VarCtx &cx) {
             for (int k = 0; k < n; ++k) lv[k] = lv[k] / ldist;
             const float sine = dot_var(n, nd, lv);
             if (sine > 0.0f) {
-                const float strength = (float)(1.0 / pow((double)ldist, (double)(n - 1)));
+                const float strength = nt_falloff(ldist, n - 1);
                 if (sc.shadows) {
                     if (fmaxf(plc.r, fmaxf(plc.g, plc.b)) * strength * sine > NT_LIGHT_THRESHOLD) {
                         var_set_ray(cx, no, lv);
@@ -1370,7 +1370,7 @@ __device__ __noinline__ Color3 composite_color_var_t(const VarCtx &cx, const Var
                 for (int k = 0; k < n; ++k) lv[k] = lv[k] / ldist;
                 const float sine = dot_var(n, nd, lv);
                 if (sine > 0.0f) {
-                    const float strength = (float)(1.0 / pow((double)ldist, (double)(n - 1)));
+                    const float strength = nt_falloff(ldist, n - 1);
                     if (sc.shadows) {
                         if (fmaxf(plc.r, fmaxf(plc.g, plc.b)) * strength * sine > NT_LIGHT_THRESHOLD) {
                             Color3 filtered = plc;
