@@ -35,7 +35,7 @@ def main():
     from ntracer_amd import distributed as ntd
     L = _lib.lib()
     st = torch.cuda.current_stream()
-    values = a.values.split(",")
+    values = a.values.split(";") if ";" in a.values else a.values.split(",")
 
     def case(name):
         world, rank, brows = 1, 0, 32
