@@ -1106,6 +1106,7 @@ int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format 
     if (int r = check_renderable(s)) return r;
     RenderGuard guard(s);
     if (int r = guard.acquire()) return r;
+    if (abort_flag && *abort_flag) return NT_ABORTED;           // (before anything touches `dest` or the device)
     int dev;
     if (int r = pick_device(opts, -1, dev)) return r;
     DeviceState *ds;
@@ -1135,7 +1136,6 @@ int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format 
     // so an abort costs what the waves in flight need to reach their next look at the word.  An aborted frame is incomplete
     // in no particular order; nothing of it is copied back -- the caller's buffer stays as it was.
     if (abort_flag) {
-        if (*abort_flag) return NT_ABORTED;
         if (!ds->abort_one) {
             if (int r = ds->abort_word.ensure(64)) return r;
             void *p = nullptr;
