@@ -218,6 +218,48 @@ def main():
     rays = float(W) * H * F * args.steps
     value = rays / wall / 1e6
 
+    # ---- the same K steps issued alternately on TWO streams (two scene handles -- each has its own device-side scratch -- and two
+    # sets of framebuffers): the tail of one call overlaps the ramp of the next, and the camera upload of the next its body.
+    # For a full frame that is 2 % (the kernel is bound by vector issue); for a rank's share of a tiled frame -- a call of a few
+    # tens of microseconds, a third of it ramp, tail and the upload in front -- it is a fifth (tools/two_stream_probe.py: a rank's
+    # eighth 67.2 -> 54.7 us a step).  At N = 1 `value` stays the one-stream figure (one kernel at a time: what the roofline and
+    # the committed profiles describe) and this is reported beside it; at N > 1 the better of the two IS `value` (`config.issue` says which), and
+    # both are reported (`one_stream`, `two_streams`).  EXACTLY K steps, barrier-bracketed, MAX over ranks, like the loop above.
+    two_ms = None
+    if not args.headline_only:
+        scene2 = tracern.BoxScene(n)
+        fb2 = torch.empty((F, frame_bytes), dtype=torch.uint8, device="cuda")
+        stream2 = torch.cuda.Stream()
+        call_args2 = (scene2._handle, C.c_void_p(fb2.data_ptr()), frame_bytes, F, step_o.ctypes.data_as(_lib.f32p), step_a.ctypes.data_as(_lib.f32p),
+                      C.byref(fst), C.byref(opts), C.c_void_p(stream2.cuda_stream))
+        both = (call_args, call_args2)
+        state = {"k": 0}
+
+        def launch_two():
+            r = render_frames(*both[state["k"] & 1])
+            state["k"] += 1
+            if r < 0:
+                _lib.check(r)
+        for _ in range(2 * args.warmup):
+            launch_two()
+        settle(torch, launch_two, args.settle_ms)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            launch_two()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        two_ms = float(tt.item()) * 1e3 / args.steps
+        del fb2
+    one_stream_value = value
+    one_stream_ms = wall * 1e3 / args.steps
+    two_wins = two_ms is not None and world > 1 and two_ms < one_stream_ms          # (both were timed: the better way to issue the steps counts)
+    if two_wins:
+        value = float(W) * H * F / (two_ms * 1e-3) / 1e6
+        wall = two_ms * 1e-3 * args.steps
+
     # ---- the same steps from a camera table resident in device memory (nt_camera_table_create: the path's cameras packed and
     # uploaded once; a call is then ONE kernel launch, nothing packed or uploaded).  Reported beside `value`, which keeps the
     # per-call camera upload of the rounds before.
@@ -318,6 +360,7 @@ def main():
                    "host_issue_ms_per_step": round(issue_s * 1e3 / args.steps, 5),
                    "settle_ms": args.settle_ms,
                    "tiling": ("%d-row bands round-robin over ranks" % band_rows) if world > 1 else "single GPU",
+                   "issue": "steps alternate between two streams (see two_streams)" if two_wins else "one stream",
                    "framebuffer": "resident in HBM (one buffer per frame)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "valu": valu,
@@ -332,6 +375,11 @@ def main():
                      "note": "BoxScene reads no scene memory: the only algorithmic HBM traffic is the packed framebuffer "
                              "(4 B/ray); the kernel is bound by instruction issue and latency, not by HBM (see DESIGN.md 4.1), so the HBM "
                              "fraction is structurally small -- `valu` is the bound that binds; avg_launch_us spans the kernels of a call"},
+        "one_stream": {"what": "the K steps on one stream, one kernel at a time (= `value` at N = 1)", "ms_per_step": round(one_stream_ms, 5),
+                       "value": round(one_stream_value, 1)},
+        "two_streams": None if two_ms is None else {
+            "what": "the K steps issued alternately on two streams (two scene handles, two sets of framebuffers): consecutive calls overlap (= `value` at N > 1 when it is the faster way)",
+            "ms_per_step": round(two_ms, 5), "value": round(float(W) * H * F / (two_ms * 1e-3) / 1e6, 1)},
         "cold_start": {"what": "the first %d steps after %d warm-up steps from an idle chip (no settling: the clock transient of the first ~50 ms of load)"
                                % (args.steps, args.warmup), "ms_per_step": round(cold_ms, 5), "value": round(float(W) * H * F / (cold_ms * 1e-3) / 1e6, 1)},
         "camera_table": None if table_ms is None else {
@@ -349,7 +397,7 @@ def main():
     if world == 1 and not args.headline_only:
         try:
             out["value_rgbf32"] = value_rgbf32(torch, ntracer_amd, tracern, _lib, origins, axes, F)
-            out["scaling_proxy"] = scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_per_step)
+            out["scaling_proxy"] = scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_per_step, two_ms)
         except Exception as e:       # never hide the headline
             out["scaling_proxy"] = {"error": repr(e)}
     if world == 1 and not args.headline_only:
@@ -491,7 +539,7 @@ def value_rgbf32(torch, ntracer_amd, tracern, _lib, origins, axes, F):
             "workload": "BoxScene(6) 1920x1080, three fp32 channels, the same %d-frame sequence, one call per step" % F}
 
 
-def scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_full):
+def scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_full, ms_full_two=None):
     """What ONE rank of `--gpus 8` does per step, timed on this GPU: rank 0's bands (8 rows each, dealt round-robin to 8
     ranks) of every frame, compact buffer.  No 8-GPU run is behind this number; it bounds the strong-scaling factor the
     kernels allow (full step / this), before any inter-GPU effect."""
@@ -533,6 +581,31 @@ def scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_f
         L.nt_camera_table_destroy(C.c_void_p(tab))
         out["camera_table_ms_per_step"] = round(mst, 5)
         out["camera_table_implied_speedup_at_8"] = round(ms_full / mst, 2)
+    # ... and the way `bench.py --gpus 8` issues a rank's steps: alternately on two streams (two scene handles, two buffers)
+    sc2 = tracern.BoxScene(6)
+    fst = fmt._as_struct()
+    fbs = [torch.empty((F, rows * fmt.pitch), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    sts = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    calls = [(s_._handle, C.c_void_p(b_.data_ptr()), rows * fmt.pitch, F, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts),
+              C.c_void_p(t_.cuda_stream)) for s_, b_, t_ in zip((sc, sc2), fbs, sts)]
+    state = {"k": 0}
+
+    def go2():
+        _lib.check(L.nt_render_frames_device(*calls[state["k"] & 1]))
+        state["k"] += 1
+    for _ in range(6):
+        go2()
+    settle(torch, go2, SETTLE_MS)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(80):
+        go2()
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) * 1e3 / 80
+    out["two_streams_ms_per_step"] = round(ms2, 5)
+    if ms_full_two:
+        out["two_streams_full_step_ms"] = round(ms_full_two, 5)
+        out["two_streams_implied_speedup_at_8"] = round(ms_full_two / ms2, 2)
     return out
 
 
