@@ -652,6 +652,37 @@ def config5(torch, dist, ntracer_amd, tracern, _lib, ntd, rank, world, local_ran
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     wall = float(el.item())
+    one_ms = wall * 1e3 / steps
+    # ... and alternately on two streams (two scene handles, two sets of framebuffers), as the headline does: for a rank's share of a
+    # frame the overlap of consecutive calls is worth more than for a whole one
+    sc2 = tracern.BoxScene(n)
+    fb2 = torch.empty((frames, own * fmt.pitch), dtype=torch.uint8, device="cuda")
+    st2 = torch.cuda.Stream()
+    calls = [(sc._handle, C.c_void_p(fb.data_ptr()), own * fmt.pitch, frames, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts),
+              C.c_void_p(st.cuda_stream)),
+             (sc2._handle, C.c_void_p(fb2.data_ptr()), own * fmt.pitch, frames, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts),
+              C.c_void_p(st2.cuda_stream))]
+    state = {"k": 0}
+
+    def go2():
+        _lib.check(L.nt_render_frames_device(*calls[state["k"] & 1]))
+        state["k"] += 1
+    for _ in range(2 * warmup):
+        go2()
+    settle(torch, go2, SETTLE_MS)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        go2()
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    two_ms = float(el.item()) * 1e3 / steps
+    del fb2
+    two_wins = world > 1 and two_ms < one_ms
+    if two_wins:
+        wall = two_ms * 1e-3 * steps
     ok = None
     gather_ms = None
     if dist is not None:
@@ -670,6 +701,8 @@ def config5(torch, dist, ntracer_amd, tracern, _lib, ntd, rank, world, local_ran
     return {"workload": "BoxScene(10) 4096x4096 RGBX8, %d cameras of the rotation per call (configs[4])" % frames, "value": round(rays / wall / 1e6, 1),
             "unit": "Mrays/s", "n_gpus": world, "ms_per_step": round(wall * 1e3 / steps, 4), "steps": steps, "frames_per_step": frames,
             "tiling": ("%d-row bands round-robin over ranks" % band_rows) if world > 1 else "single GPU", "scaling": "strong",
+            "issue": "steps alternate between two streams" if two_wins else "one stream", "one_stream_ms_per_step": round(one_ms, 4),
+            "two_streams_ms_per_step": round(two_ms, 4),
             "gather_ms_per_frame": None if gather_ms is None else round(gather_ms, 3), "gather_verified_equal_to_whole_frame": ok}
 
 
