@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
 // --------------------------------------------------------------------------------------
 // BoxScene, run-time n, packed plain RGB (RGBX8 & co.): the structure of box_tile_kernel (nt_box.hpp) with the n-vectors in
 // LDS.  A block = 64 columns x 32 rows (four waves of eight rows); one wave works out the stretch codes of the tile
-// (box_stretch_code_var: what box_stretch_code computes, with loops over n); then every lane builds forward + right*sx
-// once (base[j], in LDS as [j][thread]) together with the three dot products that give |dir|^2 as a quadratic in sy, and
+// (box_stretch_code_var: what box_stretch_code computes, with loops over n); then every lane works out the three dot products
+// of forward + right*sx that give |dir|^2 as a quadratic in sy (the vector itself is recomputed where a row needs it), and
 //   * rows the codes call background or one face throughout cost a handful of operations per pixel WHATEVER n is
 //     (guarded rsq quantisation as in box_tile_kernel),
 //   * the others are evaluated ray by ray like box_kernel_var does (the reference's arithmetic on the faces in a near-tie).
@@ -202,13 +202,16 @@ __device__ __forceinline__ uint32_t box_stretch_code_var(int n, const float *cam
 
 __global__ __launch_bounds__(256) void box_rows_kernel_var(NtCamera cam, NtTarget tg) {
     constexpr int R = 8;
-    extern __shared__ float lds_var[];   // base [n][256], dirs [n][256], camera rows [4][n], codes [4]
+    // dirs [n][256], camera rows [4][n], codes [4].  (Until round 3 `forward + right*sx` sat in LDS as well, [n][256]: with it a
+    // block needed 2n KB, and from n = 25 on it was LDS that set the occupancy -- two blocks a CU at n = 32, one at n = 64, where a
+    // wave alone issues an instruction every 8.4 cycles.  The two operations are simply done again where the value is used.)
+    extern __shared__ float lds_var[];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = cam.n;
-    float *base = lds_var + tid, *dirs = lds_var + (size_t)n * 256 + tid;          // component j at [j * 256]
-    float *camrow = lds_var + (size_t)2 * n * 256;
+    float *dirs = lds_var + tid;          // component j at [j * 256]
+    float *camrow = lds_var + (size_t)n * 256;
     uint32_t *s_code = reinterpret_cast<uint32_t *>(camrow + 4 * n);
     {
         const float *src = cam.buf ? cam.buf + (size_t)blockIdx.z * 4 * n : nullptr;
@@ -257,12 +260,11 @@ __global__ __launch_bounds__(256) void box_rows_kernel_var(NtCamera cam, NtTarge
     float bb = 0.0f, bu = 0.0f, uu = 0.0f;
     for (int j = 0; j < n; ++j) {
         const float b = fwd[j] + right[j] * sx;
-        base[j * 256] = b;
         bb = fmaf(b, b, bb);
         bu = fmaf(b, up[j], bu);
         uu = fmaf(up[j], up[j], uu);
     }
-    const float base0 = base[0], up0 = up[0];
+    const float base0 = fwd[0] + right[0] * sx, up0 = up[0];
     const float m2bu = -2.0f * bu;
     // (the quadratic's error grows with n: (3.7n + 4) * 2^-24 relative -- the guard below is sized for it)
     const bool fastsq = __builtin_amdgcn_ballot_w64(!(bu * bu <= bb * uu * 0.0625f)) == 0ull;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void box_rows_kernel_var(NtCamera cam, NtTarge
         if (fastsq && code <= 13u) {
             // background (code 0) or face K = code - 1 throughout: |x| / |dir| from x = dir[0] or dir[K] alone
             const int K = code == 0u ? 0 : (int)code - 1;
-            const float xk = (code == 0u ? base0 : base[K * 256]) - (code == 0u ? up0 : up[K]) * sy;       // dir[K], bit for bit
+            const float xk = (code == 0u ? base0 : fwd[K] + right[K] * sx) - (code == 0u ? up0 : up[K]) * sy;       // dir[K], bit for bit
             const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
             const float t = (fabsf(xk) * __builtin_amdgcn_rsqf(sqa)) * maxv, th = t * 0.5f;
             const bool clear = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > fmaf(t, guard, guard) &&
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void box_rows_kernel_var(NtCamera cam, NtTarge
         // last-reached one), with the direction in `dirs`
         float sq = 0.0f;
         for (int j = 0; j < n; ++j) {
-            const float v = base[j * 256] - up[j] * sy;
+            const float v = (fwd[j] + right[j] * sx) - up[j] * sy;
             dirs[j * 256] = v;
             sq = j == 0 ? v * v : sq + v * v;
         }
@@ -1616,7 +1618,7 @@ int nt_launch_box(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &t
         case 24: nt_box_fixed_24(li, cam, tg); break;
         default: {
             // packed plain RGB of <= 10 bits in one aligned dword: the rows kernel (codes + lean loops), if its n-vectors fit LDS
-            const size_t lds_rows = ((size_t)2 * li.n * 256 + (size_t)4 * li.n + 4) * sizeof(float);
+            const size_t lds_rows = ((size_t)li.n * 256 + (size_t)4 * li.n + 4) * sizeof(float);
             const char *er = getenv("NTRACER_BOX_VAR_ROWS");
             if (!tg.colors_out && tg.plain_bits != 0u && tg.plain_bits <= 10u && tg.bpp == 4 && tg.aligned4 && lds_rows <= 160 * 1024 &&
                 !(er && atoi(er) == 0)) {

@@ -118,7 +118,7 @@ def _stress_cameras(n, rng):
     return cams
 
 
-@pytest.mark.parametrize("n", [3, 4, 6, 8, 10, 11, 13, 15, 16, 20, 21, 24, 27])
+@pytest.mark.parametrize("n", [3, 4, 6, 8, 10, 11, 13, 15, 16, 20, 21, 24, 27, 40, 64])
 def test_box_stress_cameras_bytes_and_floats_equal_oracle(n):
     """The BoxScene kernel sorts rays into clear misses, clear hits and unclear ones, and only the last get the
     reference-ordered evaluation; quantised formats also skip the sqrt and the division away from rounding
