@@ -350,6 +350,11 @@ def main():
         hc = prof["headline_call"]
         traffic = hc["write_bytes_per_call"] + hc["fetch_bytes_per_call_corrected"]
         valu = valu_bound(hc, kernel_us)
+    elif prof and world == 8 and F == 160 and prof.get("band8_call", {}).get("rows") == own_rows:
+        # a rank's launch of an 8-GPU step was profiled too (on one GPU: tools/band_proxy.py --world 8)
+        hc = prof["band8_call"]
+        traffic = hc["write_bytes_per_call"] + hc["fetch_bytes_per_call_corrected"]
+        valu = valu_bound(hc, kernel_us)
     out = {
         "metric": "Mrays/s (primary+shadow), 6-D hypercube @1920x1080",
         "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

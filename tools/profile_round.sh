@@ -39,6 +39,10 @@ cp $(ls $raw/c4kt/*/*_kernel_stats.csv | head -1) $out/${tag}_config4_kernel_sta
 echo "[5] the one-eighth band of the headline workload (what a rank of an 8-GPU run does)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/b8 -- python3 $root/tools/band_proxy.py --world 8 > $raw/b8.log 2>&1
 cp $(ls $raw/b8/*/*_kernel_stats.csv | head -1) $out/${tag}_band8_kernel_stats.csv
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $raw/b8w -- python3 $root/tools/band_proxy.py --world 8 --steps 5 --warmup 2 > $raw/b8w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $raw/b8f -- python3 $root/tools/band_proxy.py --world 8 --steps 5 --warmup 2 > $raw/b8f.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $raw/b8sq -- python3 $root/tools/band_proxy.py --world 8 --steps 5 --warmup 2 > $raw/b8sq.log 2>&1
+rocprofv3 --pmc $CLS --output-format csv -d $raw/b8cls -- python3 $root/tools/band_proxy.py --world 8 --steps 5 --warmup 2 > $raw/b8cls.log 2>&1
 echo "[6] the 120-cell with lights and shadows at 1920x1080 (packet pass + shading pass): trace, SQ counters, classes, bytes"
 SH="python3 $root/tools/run_shadow.py 1920 1080 8"
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/shkt -- $SH > $raw/shkt.log 2>&1
