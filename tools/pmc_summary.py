@@ -133,7 +133,7 @@ if c4:
     k, v = sorted(c4.items())[0]
     summary["config4_call"] = {"kernel": k, "frames_per_call": 8, **{a: b for a, b in v.items()}}
 # kernel durations of the traced runs, per (kernel, grid): the bench mixes full-frame, one-eighth-band and fp32 calls
-for d, name in (("kt", "bench"), ("b8", "band8")):
+for d, name in (("kt", "bench"), ("ktall", "bench_all"), ("b8", "band8")):
     rows = collections.defaultdict(list)
     for f in newest(glob.glob(os.path.join(raw, d, "*", "*_kernel_trace.csv"))):
         for r in csv.DictReader(open(f)):
