@@ -861,8 +861,6 @@ __device__ __forceinline__ unsigned long long box_stretch_code2(const float (&or
         if (code == 15u && !((tn - tn2) * fabsf(vK) > m)) code = 14u;
         if (code >= 14u) {
             if (sets != nullptr && N <= 10) {
-                // (the ranges are worked out anew in each of the three passes rather than kept: this is a rare path, and 2N more
-                // live registers would set the whole kernel's allocation)
                 auto range = [&](int j, float &A, float &B, float &vabs) {
                     const float va = vc[j] - g[j], vb = vc[j] + g[j];
                     const float num = (vc[j] < 0.0f ? 1.0f : -1.0f) - org[j];
@@ -873,21 +871,21 @@ __device__ __forceinline__ unsigned long long box_stretch_code2(const float (&or
                     B = same ? hi + fabsf(hi) * 1e-6f : INFINITY;
                     vabs = same ? fabsf(vc[j]) - g[j] : 0.0f;                  // (the smaller of |va|, |vb|)
                 };
+                // (the ranges are kept for the two passes that follow: with interleaved rows nearly every wave of the middle strips
+                // has a stretch that needs its sets, so this is no longer a rare path -- and working each range out three times, two
+                // v_rcp_f32 each, was a twentieth of the kernel's vector instructions; 3N registers that are dead again before
+                // the row loops begin)
+                float rA[N], rB[N], rV[N];
                 float TN = -INFINITY, TH = -INFINITY;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    float A, B, va_;
-                    range(j, A, B, va_);
-                    TN = nt_vmax(TN, A);
-                    TH = nt_vmax(TH, B);
+                    range(j, rA[j], rB[j], rV[j]);
+                    TN = nt_vmax(TN, rA[j]);
+                    TH = nt_vmax(TH, rB[j]);
                 }
                 float vmin = INFINITY;                  // the smallest |v_j| an axis that can be last has anywhere in the stretch
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    float A, B, va_;
-                    range(j, A, B, va_);
-                    vmin = B >= TN ? nt_vmin(vmin, va_) : vmin;
-                }
+                for (int j = 0; j < N; ++j) vmin = rB[j] >= TN ? nt_vmin(vmin, rV[j]) : vmin;
                 const float M = m * __builtin_amdgcn_rcpf(vmin) * (1.0f + 1e-5f);
                 // T, and the earliest entry of any of its faces for any ray: every test the redo kernel makes is made at a
                 // tau in [t_lo, t_hi]
@@ -896,11 +894,9 @@ __device__ __forceinline__ unsigned long long box_stretch_code2(const float (&or
                 const float t_hi = TH;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    float A, B, va_;
-                    range(j, A, B, va_);
-                    const bool inT = B >= TN - M;
+                    const bool inT = rB[j] >= TN - M;
                     T |= inT ? 1u << j : 0u;
-                    t_lo = inT ? nt_vmin(t_lo, A) : t_lo;
+                    t_lo = inT ? nt_vmin(t_lo, rA[j]) : t_lo;
                 }
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
