@@ -59,3 +59,21 @@ def test_bare_bench_gpus_2_on_one_card():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["delivery"]["verified_equal_to_single_gpu_frame"] is True
     assert out["config5"]["n_gpus"] == 2 and out["config5"]["gather_verified_equal_to_whole_frame"] is True and out["config5"]["value"] > 0
+
+
+def test_committed_profile_gives_an_issue_bound_below_one():
+    """bench.py's `roofline.valu` comes from the committed rocprofv3 passes (profiles/r03_pmc_summary.json): instruction counts
+    by class against the kernel's own cycle count.  Whatever the pricing of the mixed classes, the fraction has to be a
+    fraction -- round 2's busy figure read 1.04."""
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = bench.load_profile()
+    assert prof is not None and prof["headline_call"]["frames_per_call"] == 160
+    for key in ("headline_call", "rgbf32_call", "config4_call", "band8_call"):
+        v = bench.valu_bound(prof[key], 100.0)
+        assert v is not None, key
+        assert 0.0 < v["frac_lo"] <= v["frac"] <= v["frac_hi"] <= 1.0, (key, v["frac_lo"], v["frac_hi"])
+        assert sum(v["by_class"].values()) == pytest.approx(v["valu_wave_insts"], rel=1e-6)
+    hc = prof["headline_call"]
+    # HBM traffic of the headline call = the framebuffers, to within a percent (no wasted re-reads)
+    assert hc["write_bytes_per_call"] + hc["fetch_bytes_per_call_corrected"] < 1.01 * hc["algorithmic_bytes_per_call"]
