@@ -460,9 +460,14 @@ __device__ __forceinline__ bool leaf_occludes(const NtCompositeDev &sc, int star
 #ifndef NT_OCCL_ATTR
 #define NT_OCCL_ATTR __noinline__
 #endif
+// (the ray travels BY VALUE: up to four dimensions that is registers -- the calling convention passes an aggregate of at most 16
+// dwords directly -- where two references to the caller's arrays were two round trips through scratch memory per component)
+template <int N> struct RayArg { float o[N], d[N]; };
 template <int N, bool STATS, bool SCALP = true>
-__device__ NT_OCCL_ATTR bool trace_occluded(const NtCompositeDev &sc, const WaveLds &w, int lane, const float (&o)[N], const float (&d)[N],
+__device__ NT_OCCL_ATTR bool trace_occluded(const NtCompositeDev &sc, const WaveLds &w, int lane, const RayArg<N> ray,
                                             float ldistance, int skip_item, int skip_lane, Stats &st) {
+    const float (&o)[N] = ray.o;
+    const float (&d)[N] = ray.d;
     setup_ray_table<N>(w, lane, o, d);
     int node = sc.root;
     int sp = 0;
@@ -735,7 +740,10 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
                     const float strength = nt_falloff(ldist, N - 1);
                     if (sc.shadows) {
                         if (fmaxf(plc.r, fmaxf(plc.g, plc.b)) * strength * sine > NT_LIGHT_THRESHOLD) {
-                            if (!trace_occluded<N, STATS, SCALP>(sc, w, lane, no, lv, ldist, hit.item, hit.lane, st)) {
+                            RayArg<N> sray;
+#pragma unroll
+                            for (int k = 0; k < N; ++k) { sray.o[k] = no[k]; sray.d[k] = lv[k]; }
+                            if (!trace_occluded<N, STATS, SCALP>(sc, w, lane, sray, ldist, hit.item, hit.lane, st)) {
                                 const Color3 filtered = cscale(plc, strength);
                                 light = cadd(light, cscale(filtered, sine));
                                 if (m[8] != 0.0f) append_specular<N>(specular, spec_a, m, filtered, d, nd, lv);
@@ -755,7 +763,10 @@ __device__ __forceinline__ Color3 composite_color(const NtCompositeDev &sc, cons
                 const float sine = -dotN<N>(nd, gdir);
                 if (sine > 0.0f) {
                     if (sc.shadows) {
-                        if (!trace_occluded<N, STATS, SCALP>(sc, w, lane, no, neg, FLT_MAX, hit.item, hit.lane, st)) {
+                        RayArg<N> sray;
+#pragma unroll
+                        for (int k = 0; k < N; ++k) { sray.o[k] = no[k]; sray.d[k] = neg[k]; }
+                        if (!trace_occluded<N, STATS, SCALP>(sc, w, lane, sray, FLT_MAX, hit.item, hit.lane, st)) {
                             light = cadd(light, cscale(glc, sine));
                             if (m[8] != 0.0f) append_specular<N>(specular, spec_a, m, glc, d, nd, neg);
                         }
