@@ -142,7 +142,10 @@ typedef struct {
                                     frames come from kernels without counters (Solids with the reference's normal handling) are
                                     drawn as always and counted by a launch of their own (the counters then describe the
                                     clean-normal traversal); scenes with transparent materials, and n > 10: NT_E_UNSUPPORTED */
-    int32_t reserved;
+    int32_t overlapped;          /* device entry points: 1 = the caller keeps two or more streams busy with calls like this one
+                                    (consecutive calls overlap on the device: the ramp and the tail of a call are filled by its
+                                    neighbours), so the library shapes its launches for throughput rather than for the time of a
+                                    call that runs alone (BoxScene: longer waves).  Never changes the pixels.  0: default */
     /* Abort for the device entry points (nt_render_device / nt_render_frames_device), which only enqueue: NULL, or a dword
        the DEVICE can read while the kernels run -- best in device memory, raised by a 4-byte copy on another stream
        (pinned host memory works too, but every block's look at it is then a PCIe round trip) -- that the caller sets

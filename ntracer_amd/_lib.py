@@ -67,7 +67,7 @@ class NtSceneParams(C.Structure):
 class NtRenderOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("band_rank", C.c_int32), ("band_world", C.c_int32), ("band_rows", C.c_int32),
                 ("compact", C.c_int32), ("strict_reference", C.c_int32), ("collect_stats", C.c_int32),
-                ("reserved", C.c_int32), ("abort_device", C.c_void_p)]
+                ("overlapped", C.c_int32), ("abort_device", C.c_void_p)]
 
 
 class NtStats(C.Structure):

@@ -299,11 +299,20 @@ int device_state(nt_scene *s, int dev, DeviceState *&out) {
     if (it == s->devs.end()) {
         auto ds = std::make_unique<DeviceState>();
         ds->device = dev;
-        HIP_TRY(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
         HIP_TRY(hipDeviceGetAttribute(&ds->cu_count, hipDeviceAttributeMultiprocessorCount, dev));
         it = s->devs.emplace(dev, std::move(ds)).first;
     }
     out = it->second.get();
+    return NT_OK;
+}
+
+// The stream of the entry points that take none (nt_render, nt_colors_at), made when one of them first needs it: a scene that
+// is only ever drawn through the device entry points -- on the caller's streams -- creates no stream of its own.  (The device
+// has a handful of hardware queues and the runtime deals its streams out over them; streams nobody uses still take their turn,
+// and two of the caller's streams that end up on one queue no longer overlap: a process that had made a dozen scenes lost the
+// overlap of alternating calls, 48 -> 88 us a step.)
+int own_stream(DeviceState *ds) {
+    if (!ds->stream) HIP_TRY(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
     return NT_OK;
 }
 
@@ -565,6 +574,7 @@ struct FrameJob {
     bool stats;
     bool strict = false;      // nt_render_opts.strict_reference
     const int *abort_word = nullptr;   // NtTarget::abort_word
+    int overlapped = 0;                // nt_render_opts::overlapped
     bool counters_pass = false;        // (enqueue's own) the statistics launch of a scene whose pixels come from the faithful kernels
     int row_begin, row_count; // owned-row range
     // probe mode
@@ -671,6 +681,8 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job_in) {
     li.cull_buf = nullptr;
     li.tie_buf = nullptr;
     li.cull_clean = 0;
+    li.tile_rows = 0;
+    li.tile_waves = 0;
     li.box_path = 1;
     if (const char *bp = getenv("NTRACER_BOX_PATH")) li.box_path = atoi(bp);
     if (const char *kc = getenv("NTRACER_COMPOSITE_KERNEL")) li.kernel_choice = atoi(kc);
@@ -820,7 +832,9 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job_in) {
                 // the waves of a column strip deal the rows out among themselves, so that the rows that need ray-by-ray work --
                 // which come in runs of dozens -- are spread over all of them instead of making a few waves ten times as long as
                 // the rest
-                const NtBoxTileGeom geom = nt_box_tile_geom(tg.width, tg.row_count, job.nframes);
+                const NtBoxTileGeom geom = nt_box_tile_geom(tg.width, tg.row_count, job.nframes, job.overlapped);
+                li.tile_rows = geom.rows;
+                li.tile_waves = geom.waves;
                 const char *eil = getenv("NTRACER_BOX_INTERLEAVE");
                 const int tile_rows = geom.rows * geom.waves;
                 tg.row_il = (tg.row_begin == 0 && !(eil && atoi(eil) == 0)) ? (tg.row_count + tile_rows - 1) / tile_rows * geom.waves : 0;
@@ -1112,6 +1126,7 @@ int nt_render(nt_scene_t *s, void *dest, size_t dest_len, const nt_image_format 
     DeviceState *ds;
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
+    if (int r = own_stream(ds)) return r;
     if (int r = use_stream(ds, ds->stream)) return r;
     if (int r = ds->framebuffer.ensure(std::max<size_t>(need, 16))) return r;
     const bool stats = opts && opts->collect_stats;
@@ -1203,6 +1218,7 @@ int nt_render_device(nt_scene_t *s, void *dest_dev, size_t dest_len, const nt_im
     job.stats = stats;
     job.strict = opts && opts->strict_reference;
     job.abort_word = opts ? (const int *)opts->abort_device : nullptr;
+    job.overlapped = opts ? opts->overlapped : 0;
     job.row_begin = 0;
     job.row_count = b.owned_rows;
     return enqueue(s, ds, job);
@@ -1269,6 +1285,7 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     job.stats = stats;
     job.strict = opts && opts->strict_reference;
     job.abort_word = opts ? (const int *)opts->abort_device : nullptr;
+    job.overlapped = opts ? opts->overlapped : 0;
     job.row_begin = 0;
     job.row_count = b.owned_rows;
     return enqueue(s, ds, job);
@@ -1350,6 +1367,7 @@ int nt_render_table_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, c
     job.stats = stats;
     job.strict = opts && opts->strict_reference;
     job.abort_word = opts ? (const int *)opts->abort_device : nullptr;
+    job.overlapped = opts ? opts->overlapped : 0;
     job.row_begin = 0;
     job.row_count = b.owned_rows;
     return enqueue(s, ds, job);
@@ -1367,6 +1385,7 @@ int nt_colors_at(nt_scene_t *s, int width, int height, int count, const int32_t 
     DeviceState *ds;
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
+    if (int r = own_stream(ds)) return r;
     if (int r = use_stream(ds, ds->stream)) return r;
     const size_t ibytes = (size_t)count * sizeof(int32_t);
     const size_t cbytes = (size_t)count * 3 * sizeof(float);

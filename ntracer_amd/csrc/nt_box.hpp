@@ -1420,7 +1420,9 @@ int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget
         // (the wave works out its own codes, and the set-up per column is shared by four times the rows) once the launch is tall
         // enough for such tiles to fit it well and has waves enough even so (four 4096 x 4096 frames are 16 384 such waves: 7 %
         // slower than with 16 rows a wave; sixteen frames: 9 % faster)
-        const NtBoxTileGeom geom = nt_box_tile_geom(tg.width, tg.row_count, li.nframes);
+        NtBoxTileGeom geom;
+        geom.rows = li.tile_rows;
+        geom.waves = li.tile_waves;
         const bool r64 = geom.rows == 64, r16 = geom.rows == 16;
         const int wpb = geom.waves;
         const int tile_rows = geom.rows * geom.waves;

@@ -170,6 +170,7 @@ struct NtLaunchInfo {
     int hit_frames;
     float *numer_buf;         // scratch for the packet kernel's plane numerators: numer_frames * n_batches * 4 floats
     int numer_frames;
+    int tile_rows, tile_waves; // BoxScene, fused path: box_tile_kernel's block shape (nt_box_tile_geom; the row table follows it)
     int box_path;             // BoxScene: 1 = fused tile kernel for the scripted formats (default), 0 = cull / box / redo kernels
     int cull_clean;           // cull_buf is all zero (the fused path's redo bitmap lives at its start)
     uint32_t *tie_buf;        // BoxScene: scratch for the tie sets of the fused path, nframes * row_count * ceil(width/64) dwords (or nullptr)
@@ -179,8 +180,12 @@ struct NtLaunchInfo {
 // box_tile_kernel's block shape for a launch, decided in one place because the host's row table (nt_api.cpp) follows it:
 // 64 rows a wave and one wave a block for tall launches with waves to spare; otherwise 16 rows a wave (8 in small launches),
 // four waves a block, or three when that leaves fewer idle waves below the last row (see launch_box_fixed).
+// `overlapped` (nt_render_opts::overlapped): the caller keeps two or more streams busy with calls like this one, so the
+// ramp and the tail of a call are filled by its neighbours.  Long waves -- whose tail is what makes them lose on a short
+// launch that runs alone -- are then the better shape from 64 rows up: a rank's 136 rows of the 160 headline frames take
+// 66 us alone with 16 x 3 and 86 with 64 x 1, 54 and 48 when consecutive calls alternate between two streams.
 struct NtBoxTileGeom { int rows, waves; };
-static inline NtBoxTileGeom nt_box_tile_geom(int width, int row_count, int nframes) {
+static inline NtBoxTileGeom nt_box_tile_geom(int width, int row_count, int nframes, int overlapped) {
     const long long cols = (width + 63) / 64;
     const long long waves8 = cols * ((row_count + 31) / 32) * nframes * 4;
     const bool r16 = waves8 >= 64 * 1024;
@@ -189,7 +194,9 @@ static inline NtBoxTileGeom nt_box_tile_geom(int width, int row_count, int nfram
         const int groups = (row_count + 15) / 16;                   // waves with rows, per column
         if ((groups + 2) / 3 * 3 < (groups + 3) / 4 * 4) wpb = 3;
     }
-    bool r64 = r16 && row_count >= 512 && cols * ((row_count + 63) / 64) * nframes >= 32 * 1024;
+    const long long waves64 = cols * ((row_count + 63) / 64) * nframes;
+    bool r64 = r16 && row_count >= 512 && waves64 >= 32 * 1024;
+    if (overlapped && r16 && row_count >= 64 && waves64 >= 8 * 1024) r64 = true;
     if (const char *e = getenv("NTRACER_BOX_R64")) r64 = r16 && atoi(e) != 0;        // (A/B)
     NtBoxTileGeom g;
     g.rows = r64 ? 64 : (r16 ? 16 : 8);

@@ -1441,6 +1441,48 @@ def test_box_kernel_paths_alternate_on_one_scene(monkeypatch):
                 assert np.array_equal(got[k], refs[k]), (n, path, il, k, int((got[k] != refs[k]).sum()))
 
 
+def test_overlapped_hint_changes_the_launch_shape_not_the_bytes():
+    """nt_render_opts.overlapped (the caller keeps several streams busy: long waves from 64 rows up) must never change a pixel:
+    a rank's eighth of 160 headline frames -- 136 rows in 8-row bands, the launch whose shape the hint changes -- and the whole
+    frames, with the hint and without, alternating on one scene, on two streams at once; three frames against the oracle."""
+    import torch
+    from ntracer_amd import distributed as ntd
+    g = fx.load("box_n6_1920x1080")
+    W, H, F = 1920, 1080, 160
+    o = np.ascontiguousarray(g["origins"][:F], np.float32)
+    a = np.ascontiguousarray(g["axes"][:F], np.float32)
+    fmt = fmt_of(W, H, fx.RGBX8)
+    fst = fmt._as_struct()
+    L = _lib.lib()
+    for world, brows in ((8, 8), (1, 32)):
+        own = ntd.owned_rows(H, 0, world, brows)
+        scenes = [tracern.BoxScene(6), tracern.BoxScene(6)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        fbs = [torch.empty((F, len(own) * fmt.pitch), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        got = {}
+        for hint in (0, 1, 0, 1):
+            opts = _lib.NtRenderOpts()
+            opts.device = -1
+            opts.band_rank, opts.band_world, opts.band_rows, opts.compact = 0, world, brows, 1
+            opts.overlapped = hint
+            for fb in fbs:
+                fb.fill_(0x5a)
+            torch.cuda.synchronize()
+            for k in range(4):                           # consecutive calls overlap: two handles, two buffers, two streams
+                _lib.check(L.nt_render_frames_device(scenes[k & 1]._handle, C.c_void_p(fbs[k & 1].data_ptr()), len(own) * fmt.pitch, F,
+                                                     o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts),
+                                                     C.c_void_p(streams[k & 1].cuda_stream)))
+            torch.cuda.synchronize()
+            assert torch.equal(fbs[0], fbs[1])
+            if hint in got:
+                assert torch.equal(got[hint], fbs[0])
+            got[hint] = fbs[0].clone()
+        assert torch.equal(got[0], got[1]), (world, int((got[0] != got[1]).sum()))
+        for k in (0, 77, 159):
+            ref = ob.OracleScene(6, o[k], a[k]).render(W, H, fx.RGBX8, threads=8)
+            assert np.array_equal(got[1][k].cpu().numpy().reshape(len(own), fmt.pitch), ref[own]), (world, k)
+
+
 def test_asking_for_statistics_does_not_change_the_pixels():
     """collect_stats on a scene with Solids: the frame still comes from the kernel that reproduces the reference's normal
     handling (the counters from a launch of their own); on a scene with transparent materials -- whose kernels keep no

@@ -18,25 +18,45 @@ from ntracer_amd import distributed as ntd  # noqa: E402
 import bench  # noqa: E402
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-g = np.load(os.path.join(ROOT, "tests", "golden", "box_n6_1920x1080.npz"))
-o = np.ascontiguousarray(g["origins"], np.float32)
-a = np.ascontiguousarray(g["axes"], np.float32)
+DIM = 6
 F, W, H = 160, 1920, 1080
+if os.environ.get("CASE") == "cfg5":                      # BASELINE configs[4]: BoxScene(10) 4096 x 4096, 16 frames a call
+    DIM, F, W, H = 10, 16, 4096, 4096
+g = np.load(os.path.join(ROOT, "tests", "golden", "box_n%d_%dx%d.npz" % (DIM, W, H)))
+sel = (np.arange(F) * (len(g["origins"]) // F)) % len(g["origins"])
+o = np.ascontiguousarray(g["origins"][sel], np.float32)
+a = np.ascontiguousarray(g["axes"][sel], np.float32)
 fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(*c) for c in bench.RGBX8])
 fst = fmt._as_struct()
 brows = bench.pick_band_rows(ntd, H, world)
 opts = _lib.NtRenderOpts()
 opts.device = 0
 opts.band_rank, opts.band_world, opts.band_rows, opts.compact = 0, world, brows, 1
+opts_ov = _lib.NtRenderOpts()
+C.memmove(C.byref(opts_ov), C.byref(opts), C.sizeof(opts))
+opts_ov.overlapped = int(os.environ.get("OVERLAPPED", "1"))          # what the several-stream legs tell the library
 own = len(ntd.owned_rows(H, 0, world, brows))
 L = _lib.lib()
-scenes = [tracern.BoxScene(6), tracern.BoxScene(6)]
-fbs = [torch.empty((F, own * fmt.pitch), dtype=torch.uint8, device="cuda") for _ in range(2)]
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-tabs = [L.nt_camera_table_create(6, F, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), 0) for _ in range(2)]
+# (other scenes of the process, each drawn once through the device entry point: do they cost the overlap?)
+others = [tracern.BoxScene(DIM) for _ in range(int(os.environ.get("EXTRA_SCENES", "0")))]
+for s_ in others:
+    t_ = torch.empty(64 * 64 * 4, dtype=torch.uint8, device="cuda")
+    f_ = ntracer_amd.ImageFormat(64, 64, [ntracer_amd.Channel(*c) for c in bench.RGBX8])._as_struct()
+    _lib.check(L.nt_render_frames_device(s_._handle, C.c_void_p(t_.data_ptr()), 64 * 64 * 4, 1, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p),
+                                         C.byref(f_), None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+torch.cuda.synchronize()
+NS = int(os.environ.get("NSTREAMS", "2"))            # streams of the "two streams" legs
+scenes = [tracern.BoxScene(DIM) for _ in range(NS)]
+fbs = [torch.empty((F, own * fmt.pitch), dtype=torch.uint8, device="cuda") for _ in range(NS)]
+for _ in range(int(os.environ.get("SKIP_STREAMS", "0"))):          # (torch hands out pool streams in turn: start further down the pool)
+    torch.cuda.Stream()
+streams = [torch.cuda.Stream() for _ in range(NS)]
+if os.environ.get("USE_NULL_STREAM", "0") != "0":
+    streams[0] = torch.cuda.current_stream()
+tabs = [L.nt_camera_table_create(DIM, F, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), 0) for _ in range(NS)]
 
 
-def call(i, table):
+def call(i, table, opts=opts):
     if table:
         _lib.check(L.nt_render_table_device(scenes[i]._handle, C.c_void_p(fbs[i].data_ptr()), own * fmt.pitch, C.c_void_p(tabs[i]), 0, F, C.byref(fst), C.byref(opts),
                                             C.c_void_p(streams[i].cuda_stream)))
@@ -52,7 +72,7 @@ for table in (False, True):
             t_end = time.perf_counter() + 0.25
             k = 0
             while time.perf_counter() < t_end:
-                call(k % 2 if two else 0, table)
+                call(k % NS if two else 0, table, opts_ov if two else opts)
                 k += 1
                 if k % 8 == 0:
                     torch.cuda.synchronize()
@@ -60,8 +80,8 @@ for table in (False, True):
             steps = 200
             t0 = time.perf_counter()
             for k in range(steps):
-                call(k % 2 if two else 0, table)
+                call(k % NS if two else 0, table, opts_ov if two else opts)
             torch.cuda.synchronize()
             res.append((time.perf_counter() - t0) / steps * 1e6)
-        print("world %d, %s, %s: %.1f us a step (best of 3: %s)" % (world, "camera table" if table else "host cameras", "two streams" if two else "one stream",
+        print("world %d, %s, %s: %.1f us a step (best of 3: %s)" % (world, "camera table" if table else "host cameras", ("%d streams" % NS) if two else "one stream",
                                                                      min(res), ", ".join("%.1f" % r for r in res)))
