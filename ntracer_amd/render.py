@@ -404,8 +404,9 @@ def _host_buffer(dest):
     return arr, n
 
 
-def _opts(device=-1, band_rank=0, band_world=1, compact=False, collect_stats=False, band_rows=0, strict_reference=None):
+def _opts(device=-1, band_rank=0, band_world=1, compact=False, collect_stats=False, band_rows=0, strict_reference=None, overlapped=False):
     o = _lib.NtRenderOpts()
+    o.overlapped = 1 if overlapped else 0
     o.device = device
     o.band_rank = band_rank
     o.band_world = band_world
@@ -443,13 +444,16 @@ class CameraTable(object):
             except Exception:
                 pass
 
-    def render(self, scene, dest, format, frame_bytes=None, band_rank=0, band_world=1, compact=False, band_rows=0, strict_reference=None):
+    def render(self, scene, dest, format, frame_bytes=None, band_rank=0, band_world=1, compact=False, band_rows=0, strict_reference=None,
+               overlapped=False):
+        """``overlapped``: the caller keeps two or more torch streams busy with calls like this one (nt_render_opts.overlapped:
+        the launches are shaped for throughput rather than for the time of a call that runs alone; same pixels)."""
         dev = _device_pointer(dest)
         if dev is None:
             raise TypeError("dest must be a torch HIP tensor")
         ptr, nbytes, index, stream = dev
         fmt = format._as_struct()
-        opts = _opts(index, band_rank, band_world, compact, False, band_rows=band_rows, strict_reference=strict_reference)
+        opts = _opts(index, band_rank, band_world, compact, False, band_rows=band_rows, strict_reference=strict_reference, overlapped=overlapped)
         if frame_bytes is None:
             frame_bytes = nbytes // self.frames
         _lib.check(_lib.lib().nt_render_table_device(scene._handle, C.c_void_p(ptr), frame_bytes, self._h, 0, self.frames, C.byref(fmt),
