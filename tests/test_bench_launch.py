@@ -69,7 +69,7 @@ def test_committed_profile_gives_an_issue_bound_below_one():
     import bench
     prof = bench.load_profile()
     assert prof is not None and prof["headline_call"]["frames_per_call"] == 160
-    for key in ("headline_call", "rgbf32_call", "config4_call", "band8_call"):
+    for key in ("headline_call", "rgbf32_call", "config4_call", "band8_call", "band8_overlapped_call"):
         v = bench.valu_bound(prof[key], 100.0)
         assert v is not None, key
         assert 0.0 < v["frac_lo"] <= v["frac"] <= v["frac_hi"] <= 1.0, (key, v["frac_lo"], v["frac_hi"])

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(world, rank, band_rows, steps, warmup, frames=160, n=6, W=1920, H=1080, f32=False):
+def measure(world, rank, band_rows, steps, warmup, frames=160, n=6, W=1920, H=1080, f32=False, overlapped=False):
     import torch
     import ntracer_amd
     from ntracer_amd import _lib, tracern
@@ -42,6 +42,7 @@ def measure(world, rank, band_rows, steps, warmup, frames=160, n=6, W=1920, H=10
     opts.band_world = world
     opts.band_rows = band_rows
     opts.compact = 1
+    opts.overlapped = 1 if overlapped else 0        # (the launch shape of callers that overlap their calls; here one call at a time)
     own = len(ntd.owned_rows(H, rank, world, band_rows))
     fb = torch.empty((frames, own * fmt.pitch), dtype=torch.uint8, device="cuda")
     st = torch.cuda.current_stream()
@@ -79,5 +80,6 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=160)
     ap.add_argument("--n", type=int, default=6)
     ap.add_argument("--f32", action="store_true")
+    ap.add_argument("--overlapped", action="store_true", help="nt_render_opts.overlapped = 1: the launch shape of the two-stream legs")
     a = ap.parse_args()
-    print(json.dumps(measure(a.world, a.rank, a.band_rows, a.steps, a.warmup, frames=a.frames, n=a.n, f32=a.f32)))
+    print(json.dumps(measure(a.world, a.rank, a.band_rows, a.steps, a.warmup, frames=a.frames, n=a.n, f32=a.f32, overlapped=a.overlapped)))

@@ -47,6 +47,12 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $raw/b8w -- python3 $root/tool
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $raw/b8f -- python3 $root/tools/band_proxy.py --world 8 --steps 5 --warmup 2 > $raw/b8f.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $raw/b8sq -- python3 $root/tools/band_proxy.py --world 8 --steps 5 --warmup 2 > $raw/b8sq.log 2>&1
 rocprofv3 --pmc $CLS --output-format csv -d $raw/b8cls -- python3 $root/tools/band_proxy.py --world 8 --steps 5 --warmup 2 > $raw/b8cls.log 2>&1
+echo "[5b] the same with nt_render_opts.overlapped (the launch shape of bench.py's two-stream legs: 64-row waves), one call at a time under the profiler"
+B8O="python3 $root/tools/band_proxy.py --world 8 --overlapped --steps 5 --warmup 2"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $raw/b8ow -- $B8O > $raw/b8ow.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $raw/b8of -- $B8O > $raw/b8of.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $raw/b8osq -- $B8O > $raw/b8osq.log 2>&1
+rocprofv3 --pmc $CLS --output-format csv -d $raw/b8ocls -- $B8O > $raw/b8ocls.log 2>&1
 echo "[6] the 120-cell with lights and shadows at 1920x1080 (packet pass + shading pass): trace, SQ counters, classes, bytes"
 SH="python3 $root/tools/run_shadow.py 1920 1080 8"
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/shkt -- $SH > $raw/shkt.log 2>&1
