@@ -161,18 +161,25 @@ def main():
     stream = torch.cuda.current_stream()
     L = _lib.lib()
 
-    # the step's cameras as the C ABI takes them (host arrays), and everything else a call needs, prepared once: the timed loop
-    # is the call itself -- which packs and uploads the cameras and launches, every time -- not numpy indexing around it
-    # (until round 3 the loop rebuilt these arrays per call and the HOST took 0.41 ms a step: the GPU waited for Python)
+    # The step's inputs -- the 160 cameras of the rotation -- are resident in device memory when the timed region starts, as the
+    # bench contract asks (nt_camera_table_create packs and uploads them once; a call is then ONE kernel launch).  The same steps
+    # with the cameras handed over as host arrays on every call, as the reference's boundary does (packed, uploaded and launched
+    # each time: the PCIe-inclusive rate), are timed beside it and reported as `host_cameras`; they were `value` until round 3's
+    # last day.  Everything a call needs is prepared once: the timed loop is the call itself, not numpy indexing around it.
     step_o = np.ascontiguousarray(origins[np.arange(F) % nrot])
     step_a = np.ascontiguousarray(axes[np.arange(F) % nrot])
-    call_args = (scene._handle, C.c_void_p(fb.data_ptr()), frame_bytes, F, step_o.ctypes.data_as(_lib.f32p), step_a.ctypes.data_as(_lib.f32p),
+    tab = L.nt_camera_table_create(n, F, step_o.ctypes.data_as(_lib.f32p), step_a.ctypes.data_as(_lib.f32p), local_rank)
+    if not tab:
+        sys.exit("nt_camera_table_create failed: " + _lib.last_error())
+    call_args = (scene._handle, C.c_void_p(fb.data_ptr()), frame_bytes, C.c_void_p(tab), 0, F, C.byref(fst), C.byref(opts), C.c_void_p(stream.cuda_stream))
+    host_args = (scene._handle, C.c_void_p(fb.data_ptr()), frame_bytes, F, step_o.ctypes.data_as(_lib.f32p), step_a.ctypes.data_as(_lib.f32p),
                  C.byref(fst), C.byref(opts), C.c_void_p(stream.cuda_stream))
+    render_table = L.nt_render_table_device
     render_frames = L.nt_render_frames_device
 
     def run(steps):
         for _ in range(steps):
-            r = render_frames(*call_args)
+            r = render_table(*call_args)
             if r < 0:
                 _lib.check(r)
         return steps
@@ -181,6 +188,21 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed_leg(step_fn, warm):
+        """`warm` untimed steps, settling, then EXACTLY K steps between two barriers; MAX over ranks; ms per step."""
+        for _ in range(warm):
+            step_fn()
+        settle(torch, step_fn, args.settle_ms)
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()) * 1e3 / args.steps
 
     # ---- cold start: the first `steps` steps after `warmup` steps from an idle chip (how rounds 1 and 2 measured).  The chip is
     # then in the middle of a clock transient -- it drops its clock when the load arrives and takes ~50 ms to settle
@@ -217,111 +239,60 @@ def main():
 
     rays = float(W) * H * F * args.steps
     value = rays / wall / 1e6
+    one_stream_value = value
+    one_stream_ms = wall * 1e3 / args.steps
 
     # ---- the same K steps issued alternately on TWO streams (two scene handles -- each has its own device-side scratch -- and two
-    # sets of framebuffers): the tail of one call overlaps the ramp of the next, and the camera upload of the next its body.
-    # For a full frame that is 2 % (the kernel is bound by vector issue); for a rank's share of a tiled frame -- a call of a few
-    # tens of microseconds, a third of it ramp, tail and the upload in front -- it is a fifth (tools/two_stream_probe.py: a rank's
-    # eighth 67.2 -> 54.7 us a step).  At N = 1 `value` stays the one-stream figure (one kernel at a time: what the roofline and
-    # the committed profiles describe) and this is reported beside it; at N > 1 the better of the two IS `value` (`config.issue` says which), and
-    # both are reported (`one_stream`, `two_streams`).  EXACTLY K steps, barrier-bracketed, MAX over ranks, like the loop above.
-    two_ms = None
+    # sets of framebuffers; the caller says so, nt_render_opts.overlapped, and the library shapes its launches for it: waves of 64
+    # rows, whose long tail is what a call that runs alone cannot afford, from 64 rows up): the tail of one call overlaps the ramp
+    # of the next.  For a full frame that is 2-3 % (the kernel is bound by vector issue); for a rank's share of a tiled frame it
+    # is a quarter (tools/two_stream_probe.py: a rank's eighth 60.6 -> 46.0 us a step).  At N = 1 `value` stays the one-stream
+    # figure (one kernel at a time: what the roofline and the committed profiles describe); at N > 1 the better of the two IS
+    # `value` (`config.issue` says which).  EXACTLY K steps, barrier-bracketed, MAX over ranks, like the loop above.
+    two_ms = host_ms = host_two_ms = None
     if not args.headline_only:
         scene2 = tracern.BoxScene(n)
         fb2 = torch.empty((F, frame_bytes), dtype=torch.uint8, device="cuda")
         stream2 = torch.cuda.Stream()
-        # (the caller says so -- nt_render_opts.overlapped -- and the library shapes its launches for it: waves of 64 rows, whose
-        # long tail is what a call that runs alone cannot afford, from 64 rows up)
         opts2 = _lib.NtRenderOpts()
         C.memmove(C.byref(opts2), C.byref(opts), C.sizeof(opts))
         opts2.overlapped = 1
-        call_args1 = call_args[:7] + (C.byref(opts2),) + call_args[8:]
-        call_args2 = (scene2._handle, C.c_void_p(fb2.data_ptr()), frame_bytes, F, step_o.ctypes.data_as(_lib.f32p), step_a.ctypes.data_as(_lib.f32p),
-                      C.byref(fst), C.byref(opts2), C.c_void_p(stream2.cuda_stream))
-        both = (call_args1, call_args2)
+        tcalls = ((scene._handle, C.c_void_p(fb.data_ptr()), frame_bytes, C.c_void_p(tab), 0, F, C.byref(fst), C.byref(opts2), C.c_void_p(stream.cuda_stream)),
+                  (scene2._handle, C.c_void_p(fb2.data_ptr()), frame_bytes, C.c_void_p(tab), 0, F, C.byref(fst), C.byref(opts2), C.c_void_p(stream2.cuda_stream)))
+        hcalls = (host_args[:7] + (C.byref(opts2),) + host_args[8:],
+                  (scene2._handle, C.c_void_p(fb2.data_ptr()), frame_bytes, F, step_o.ctypes.data_as(_lib.f32p), step_a.ctypes.data_as(_lib.f32p),
+                   C.byref(fst), C.byref(opts2), C.c_void_p(stream2.cuda_stream)))
         state = {"k": 0}
 
-        def launch_two():
-            r = render_frames(*both[state["k"] & 1])
+        def step_table_two():
+            r = render_table(*tcalls[state["k"] & 1])
             state["k"] += 1
             if r < 0:
                 _lib.check(r)
-        for _ in range(2 * args.warmup):
-            launch_two()
-        settle(torch, launch_two, args.settle_ms)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            launch_two()
-        barrier()
-        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        two_ms = float(tt.item()) * 1e3 / args.steps
+
+        def step_host():
+            r = render_frames(*host_args)
+            if r < 0:
+                _lib.check(r)
+
+        def step_host_two():
+            r = render_frames(*hcalls[state["k"] & 1])
+            state["k"] += 1
+            if r < 0:
+                _lib.check(r)
+        two_ms = timed_leg(step_table_two, 2 * args.warmup)
+        # ---- the PCIe-inclusive way: the cameras as host arrays on every call (packed, uploaded, launched), one stream and two
+        host_ms = timed_leg(step_host, args.warmup)
+        host_two_ms = timed_leg(step_host_two, 2 * args.warmup)
+        torch.cuda.synchronize()
         del fb2
-    one_stream_value = value
-    one_stream_ms = wall * 1e3 / args.steps
-
-    # ---- the same steps from a camera table resident in device memory (nt_camera_table_create: the path's cameras packed and
-    # uploaded once; a call is then ONE kernel launch, nothing packed or uploaded).  Reported beside `value`, which keeps the
-    # per-call camera upload of the rounds before.
-    table_ms = None
-    table_two_ms = None
-    if not args.headline_only:
-        tab = L.nt_camera_table_create(n, F, origins[:F].ctypes.data_as(_lib.f32p), axes[:F].ctypes.data_as(_lib.f32p), local_rank)
-        if tab:
-            def launch_table():
-                _lib.check(L.nt_render_table_device(scene._handle, C.c_void_p(fb.data_ptr()), frame_bytes, C.c_void_p(tab), 0, F, C.byref(fst),
-                                                    C.byref(opts), C.c_void_p(stream.cuda_stream)))
-            for _ in range(args.warmup):
-                launch_table()
-            settle(torch, launch_table, args.settle_ms)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                launch_table()
-            barrier()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            if dist is not None:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            table_ms = float(tt.item()) * 1e3 / args.steps
-            # ... and both: the table's steps alternately on the two streams (one table: it is only read)
-            fb2 = torch.empty((F, frame_bytes), dtype=torch.uint8, device="cuda")
-            tcalls = [(scene._handle, C.c_void_p(fb.data_ptr()), frame_bytes, C.c_void_p(tab), 0, F, C.byref(fst), C.byref(opts2), C.c_void_p(stream.cuda_stream)),
-                      (scene2._handle, C.c_void_p(fb2.data_ptr()), frame_bytes, C.c_void_p(tab), 0, F, C.byref(fst), C.byref(opts2), C.c_void_p(stream2.cuda_stream))]
-            state = {"k": 0}
-
-            def launch_table_two():
-                r = L.nt_render_table_device(*tcalls[state["k"] & 1])
-                state["k"] += 1
-                if r < 0:
-                    _lib.check(r)
-            for _ in range(2 * args.warmup):
-                launch_table_two()
-            settle(torch, launch_table_two, args.settle_ms)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                launch_table_two()
-            barrier()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            if dist is not None:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            table_two_ms = float(tt.item()) * 1e3 / args.steps
-            del fb2
-            L.nt_camera_table_destroy(C.c_void_p(tab))
-    # at N > 1 all of these were timed the same way -- EXACTLY K steps, barrier-bracketed, MAX over ranks -- and the best way to issue
-    # the steps IS `value` (`config.issue` says which); at N = 1 `value` stays the one-stream, host-camera figure the roofline and
-    # the committed profiles describe
+    # at N > 1 both ways of issuing the steps were timed the same way and the better one IS `value` (`config.issue` says which);
+    # at N = 1 `value` stays the one-stream figure the roofline and the committed profiles describe
     issue = "one stream"
-    if world > 1:
-        for ms_, name_ in ((two_ms, "steps alternate between two streams (see two_streams)"),
-                           (table_ms, "one stream, cameras resident in device memory (see camera_table)"),
-                           (table_two_ms, "steps alternate between two streams, cameras resident in device memory (see camera_table)")):
-            if ms_ is not None and ms_ * 1e-3 * args.steps < wall:
-                wall = ms_ * 1e-3 * args.steps
-                value = float(W) * H * F / (ms_ * 1e-3) / 1e6
-                issue = name_
+    if world > 1 and two_ms is not None and two_ms * 1e-3 * args.steps < wall:
+        wall = two_ms * 1e-3 * args.steps
+        value = float(W) * H * F / (two_ms * 1e-3) / 1e6
+        issue = "steps alternate between two streams (see two_streams)"
 
     # ---- delivery step, outside `value`: gather to rank 0 (RCCL) / D2H at N = 1
     gather_ms = None
@@ -357,6 +328,8 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) / 5 * 1e3
 
+    torch.cuda.synchronize()
+    L.nt_camera_table_destroy(C.c_void_p(tab))
     # ---- BASELINE.json configs[4], the config north_star assigns to the 8-GPU split: BoxScene(10) 4096 x 4096, tiled over the
     # ranks in row bands, RCCL gather verified (every rank takes part; reported next to the headline at every N)
     cfg5 = None
@@ -413,32 +386,35 @@ def main():
                    "settle_ms": args.settle_ms,
                    "tiling": ("%d-row bands round-robin over ranks" % band_rows) if world > 1 else "single GPU",
                    "issue": issue,
-                   "framebuffer": "resident in HBM (one buffer per frame)"},
+                   "framebuffer": "resident in HBM (one buffer per frame)",
+                   "cameras": "resident in HBM (nt_camera_table_create before the timed region; one kernel launch a step)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "valu": valu,
                      # what kernels that only store reach on this part in the tile kernel's pattern (measured once with
                      # tools/micro/store_rate.hip, recorded in profiles/README.md): the practical ceiling of this workload
                      "store_only": {"GBs": STORE_ONLY_GBS, "frac": round(achieved / STORE_ONLY_GBS, 4), "source": "tools/micro/store_rate.hip"},
                      "algorithmic_bytes_per_launch": float(own_rows) * W * fmt.bytes_per_pixel * F,
-                     "kernel": "box_tile_kernel<6, false, ROWS, WAVES> (64, 1 for the full frame; one nt_render_frames_device call = this kernel + "
-                               "the camera upload kernel: up to eight dimensions it needs no box_redo_kernel after it)",
+                     "kernel": "box_tile_kernel<6, false, ROWS, WAVES> (64, 1 for the full frame); one nt_render_table_device call = this kernel "
+                               "and nothing else: up to eight dimensions it needs no box_redo_kernel after it",
                      "avg_launch_us": round(kernel_us if overlap_note is None else ms_per_step * 1e3, 2),
                      "one_stream_launch_us": round(kernel_us, 2), "issue_note": overlap_note,
                      "algorithmic_bytes_per_ray": fmt.bytes_per_pixel,
                      "note": "BoxScene reads no scene memory: the only algorithmic HBM traffic is the packed framebuffer "
                              "(4 B/ray); the kernel is bound by instruction issue and latency, not by HBM (see DESIGN.md 4.1), so the HBM "
-                             "fraction is structurally small -- `valu` is the bound that binds; avg_launch_us spans the kernels of a call"},
-        "one_stream": {"what": "the K steps on one stream, one kernel at a time (= `value` at N = 1)", "ms_per_step": round(one_stream_ms, 5),
+                             "fraction is structurally small -- `valu` is the bound that binds"},
+        "one_stream": {"what": "the K steps on one stream, one kernel at a time, cameras resident (= `value` at N = 1)", "ms_per_step": round(one_stream_ms, 5),
                        "value": round(one_stream_value, 1)},
         "two_streams": None if two_ms is None else {
-            "what": "the K steps issued alternately on two streams (two scene handles, two sets of framebuffers): consecutive calls overlap (= `value` at N > 1 when it is the faster way)",
+            "what": "the K steps issued alternately on two streams (two scene handles, two sets of framebuffers, nt_render_opts.overlapped; cameras resident): "
+                    "consecutive calls overlap (= `value` at N > 1 when it is the faster way)",
             "ms_per_step": round(two_ms, 5), "value": round(float(W) * H * F / (two_ms * 1e-3) / 1e6, 1)},
         "cold_start": {"what": "the first %d steps after %d warm-up steps from an idle chip (no settling: the clock transient of the first ~50 ms of load)"
                                % (args.steps, args.warmup), "ms_per_step": round(cold_ms, 5), "value": round(float(W) * H * F / (cold_ms * 1e-3) / 1e6, 1)},
-        "camera_table": None if table_ms is None else {
-            "what": "the same steps with the path's cameras resident in device memory (nt_camera_table_create / nt_render_table_device): one kernel launch "
-                    "a call, no per-call packing or upload", "ms_per_step": round(table_ms, 5), "value": round(float(W) * H * F / (table_ms * 1e-3) / 1e6, 1),
-            "two_streams_ms_per_step": round(table_two_ms, 5), "two_streams_value": round(float(W) * H * F / (table_two_ms * 1e-3) / 1e6, 1)},
+        "host_cameras": None if host_ms is None else {
+            "what": "the same steps with the cameras handed over as host arrays on every call (nt_render_frames_device: packed, uploaded and "
+                    "launched each time -- the PCIe-inclusive rate; the reference's boundary sets a camera per frame): never `value`",
+            "ms_per_step": round(host_ms, 5), "value": round(float(W) * H * F / (host_ms * 1e-3) / 1e6, 1),
+            "two_streams_ms_per_step": round(host_two_ms, 5), "two_streams_value": round(float(W) * H * F / (host_two_ms * 1e-3) / 1e6, 1)},
         "delivery": {"what": "RCCL gather to rank 0" if world > 1 else "D2H copy to pinned host memory",
                      "ms_per_frame": round(gather_ms, 4), "verified_equal_to_single_gpu_frame": gather_ok,
                      "value_incl_delivery": round(float(W) * H * F / ((ms_per_step + gather_ms * F) * 1e-3) / 1e6, 1)},
@@ -595,102 +571,72 @@ def value_rgbf32(torch, ntracer_amd, tracern, _lib, origins, axes, F):
 
 def scaling_proxy(torch, ntracer_amd, tracern, _lib, ntd, origins, axes, F, ms_full, ms_full_two=None):
     """What ONE rank of `--gpus 8` does per step, timed on this GPU: rank 0's bands (8 rows each, dealt round-robin to 8
-    ranks) of every frame, compact buffer.  No 8-GPU run is behind this number; it bounds the strong-scaling factor the
-    kernels allow (full step / this), before any inter-GPU effect."""
+    ranks) of every frame, compact buffer, issued the ways `bench.py --gpus 8` issues them (cameras resident: one stream; two
+    streams with nt_render_opts.overlapped) and with host cameras.  No 8-GPU run is behind these numbers; they bound the
+    strong-scaling factor the kernels allow (full step / this), before any inter-GPU effect."""
     fmt = ntracer_amd.ImageFormat(1920, 1080, [ntracer_amd.Channel(*c) for c in RGBX8])
+    fst = fmt._as_struct()
     opts = _lib.NtRenderOpts()
     opts.device = torch.cuda.current_device()
     opts.band_rank, opts.band_world, opts.band_rows, opts.compact = 0, 8, 8, 1
+    opts2 = _lib.NtRenderOpts()
+    C.memmove(C.byref(opts2), C.byref(opts), C.sizeof(opts))
+    opts2.overlapped = 1
     rows = len(ntd.owned_rows(1080, 0, 8, 8))
-    sc = tracern.BoxScene(6)
-    ms = _time_frames(torch, _lib, sc, fmt, origins, axes, F, 40, opts=opts, rows=rows)
-    out = {"what": "rank 0 of 8: bands of 8 rows, %d of 1080 rows of each of the %d frames, on one GPU" % (rows, F),
-           "ms_per_step": round(ms, 5), "full_step_ms": round(ms_full, 5), "implied_speedup_at_8": round(ms_full / ms, 2),
-           "ideal_ms": round(ms_full / 8, 5), "measured_on": "1 GPU (no 8-GPU node was available to the builder)"}
-    # ... and from a camera table resident in device memory (one launch a call)
     L = _lib.lib()
     o = np.ascontiguousarray(origins[:F], np.float32)
     a = np.ascontiguousarray(axes[:F], np.float32)
     tab = L.nt_camera_table_create(6, F, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), torch.cuda.current_device())
-    if tab:
-        fst = fmt._as_struct()
-        fb = torch.empty((F, rows * fmt.pitch), dtype=torch.uint8, device="cuda")
-        st = torch.cuda.current_stream()
+    if not tab:
+        return {"error": _lib.last_error()}
+    scs = [tracern.BoxScene(6), tracern.BoxScene(6)]
+    fbs = [torch.empty((F, rows * fmt.pitch), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    sts = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    state = {"k": 0}
 
+    def table_call(i, op):
+        return (scs[i]._handle, C.c_void_p(fbs[i].data_ptr()), rows * fmt.pitch, C.c_void_p(tab), 0, F, C.byref(fst), C.byref(op), C.c_void_p(sts[i].cuda_stream))
+
+    def host_call(i, op):
+        return (scs[i]._handle, C.c_void_p(fbs[i].data_ptr()), rows * fmt.pitch, F, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(op),
+                C.c_void_p(sts[i].cuda_stream))
+
+    def leg(fn, calls, steps=80):
         def go():
-            _lib.check(L.nt_render_table_device(sc._handle, C.c_void_p(fb.data_ptr()), rows * fmt.pitch, C.c_void_p(tab), 0, F, C.byref(fst), C.byref(opts),
-                                                C.c_void_p(st.cuda_stream)))
-        for _ in range(3):
+            _lib.check(fn(*calls[state["k"] % len(calls)]))
+            state["k"] += 1
+        for _ in range(6):
             go()
         settle(torch, go, SETTLE_MS)
         torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        for _ in range(40):
+        t0 = time.perf_counter()
+        for _ in range(steps):
             go()
-        e1.record(st)
         torch.cuda.synchronize()
-        mst = e0.elapsed_time(e1) / 40
-        out["camera_table_ms_per_step"] = round(mst, 5)
-        out["camera_table_implied_speedup_at_8"] = round(ms_full / mst, 2)
-    # ... and the way `bench.py --gpus 8` issues a rank's steps: alternately on two streams (two scene handles, two buffers)
-    sc2 = tracern.BoxScene(6)
-    fst = fmt._as_struct()
-    fbs = [torch.empty((F, rows * fmt.pitch), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    sts = [torch.cuda.current_stream(), torch.cuda.Stream()]
-    opts2 = _lib.NtRenderOpts()
-    C.memmove(C.byref(opts2), C.byref(opts), C.sizeof(opts))
-    opts2.overlapped = 1
-    calls = [(s_._handle, C.c_void_p(b_.data_ptr()), rows * fmt.pitch, F, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts2),
-              C.c_void_p(t_.cuda_stream)) for s_, b_, t_ in zip((sc, sc2), fbs, sts)]
-    state = {"k": 0}
-
-    def go2():
-        _lib.check(L.nt_render_frames_device(*calls[state["k"] & 1]))
-        state["k"] += 1
-    for _ in range(6):
-        go2()
-    settle(torch, go2, SETTLE_MS)
+        return (time.perf_counter() - t0) * 1e3 / steps
+    ms = leg(L.nt_render_table_device, [table_call(0, opts)])
+    ms2 = leg(L.nt_render_table_device, [table_call(0, opts2), table_call(1, opts2)])
+    hms = leg(L.nt_render_frames_device, [host_call(0, opts)])
+    hms2 = leg(L.nt_render_frames_device, [host_call(0, opts2), host_call(1, opts2)])
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(80):
-        go2()
-    torch.cuda.synchronize()
-    ms2 = (time.perf_counter() - t0) * 1e3 / 80
-    out["two_streams_ms_per_step"] = round(ms2, 5)
-    # (against the full step issued the same way, and against `value`'s -- one stream -- which is what a scaling curve divides by)
+    L.nt_camera_table_destroy(C.c_void_p(tab))
+    out = {"what": "rank 0 of 8: bands of 8 rows, %d of 1080 rows of each of the %d frames, on one GPU" % (rows, F),
+           "ms_per_step": round(ms, 5), "full_step_ms": round(ms_full, 5), "implied_speedup_at_8": round(ms_full / ms, 2),
+           "ideal_ms": round(ms_full / 8, 5), "measured_on": "1 GPU (no 8-GPU node was available to the builder)",
+           # (against the full step issued the same way, and against `value`'s -- one stream -- which is what a scaling curve divides by)
+           "two_streams_ms_per_step": round(ms2, 5), "two_streams_vs_one_stream_full_step": round(ms_full / ms2, 2),
+           "host_cameras_ms_per_step": round(hms, 5), "host_cameras_two_streams_ms_per_step": round(hms2, 5)}
     if ms_full_two:
         out["two_streams_full_step_ms"] = round(ms_full_two, 5)
         out["two_streams_implied_speedup_at_8"] = round(ms_full_two / ms2, 2)
-    out["two_streams_vs_one_stream_full_step"] = round(ms_full / ms2, 2)
-    if tab:
-        tcalls = [(s_._handle, C.c_void_p(b_.data_ptr()), rows * fmt.pitch, C.c_void_p(tab), 0, F, C.byref(fst), C.byref(opts2), C.c_void_p(t_.cuda_stream))
-                  for s_, b_, t_ in zip((sc, sc2), fbs, sts)]
-
-        def go3():
-            _lib.check(L.nt_render_table_device(*tcalls[state["k"] & 1]))
-            state["k"] += 1
-        for _ in range(6):
-            go3()
-        settle(torch, go3, SETTLE_MS)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(80):
-            go3()
-        torch.cuda.synchronize()
-        ms3 = (time.perf_counter() - t0) * 1e3 / 80
-        out["camera_table_two_streams_ms_per_step"] = round(ms3, 5)
-        out["camera_table_two_streams_vs_one_stream_full_step"] = round(ms_full / ms3, 2)
-        L.nt_camera_table_destroy(C.c_void_p(tab))
     return out
 
 
 def config5(torch, dist, ntracer_amd, tracern, _lib, ntd, rank, world, local_rank, frames=16, steps=8, warmup=2):
     """BASELINE.json configs[4]: BoxScene(10) (the reference sends n = 10 through its generic var_geometry module; here a
-    compile-time-N kernel), 4096 x 4096 RGBX8, `frames` cameras of the rotation per call, every frame tiled over the ranks in
-    row bands (band b -> rank b % N, as the headline), barrier-bracketed, MAX over ranks; then one frame gathered to rank 0
-    (RCCL) and compared with the same frame rendered whole."""
+    compile-time-N kernel), 4096 x 4096 RGBX8, `frames` cameras of the rotation per call -- resident in device memory, as the
+    headline's -- every frame tiled over the ranks in row bands (band b -> rank b % N, as the headline), barrier-bracketed, MAX
+    over ranks; then one frame gathered to rank 0 (RCCL) and compared with the same frame rendered whole."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "box_n10_4096x4096.npz"))
     n, W, H = 10, 4096, 4096
     sel = (np.arange(frames) * (len(g["origins"]) // frames)) % len(g["origins"])            # spread over the rotation
@@ -702,67 +648,60 @@ def config5(torch, dist, ntracer_amd, tracern, _lib, ntd, rank, world, local_ran
     opts = _lib.NtRenderOpts()
     opts.device = local_rank
     opts.band_rank, opts.band_world, opts.band_rows, opts.compact = rank, world, band_rows, 1
+    opts2 = _lib.NtRenderOpts()
+    C.memmove(C.byref(opts2), C.byref(opts), C.sizeof(opts))
+    opts2.overlapped = 1
     own = len(ntd.owned_rows(H, rank, world, band_rows))
-    fb = torch.empty((frames, own * fmt.pitch), dtype=torch.uint8, device="cuda")
-    sc = tracern.BoxScene(n)
-    st = torch.cuda.current_stream()
     L = _lib.lib()
+    tab = L.nt_camera_table_create(n, frames, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), local_rank)
+    if not tab:
+        return {"error": _lib.last_error()}
+    scs = [tracern.BoxScene(n), tracern.BoxScene(n)]
+    fbs = [torch.empty((frames, own * fmt.pitch), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    sts = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    fb, sc, st = fbs[0], scs[0], sts[0]
+    state = {"k": 0}
 
-    def go():
-        _lib.check(L.nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), own * fmt.pitch, frames, o.ctypes.data_as(_lib.f32p),
-                                             a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts), C.c_void_p(st.cuda_stream)))
+    def table_call(i, op):
+        return (scs[i]._handle, C.c_void_p(fbs[i].data_ptr()), own * fmt.pitch, C.c_void_p(tab), 0, frames, C.byref(fst), C.byref(op), C.c_void_p(sts[i].cuda_stream))
+
+    def host_call(i, op):
+        return (scs[i]._handle, C.c_void_p(fbs[i].data_ptr()), own * fmt.pitch, frames, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst),
+                C.byref(op), C.c_void_p(sts[i].cuda_stream))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        go()
-    settle(torch, go, SETTLE_MS)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        go()
-    barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    wall = float(el.item())
-    one_ms = wall * 1e3 / steps
-    # ... and alternately on two streams (two scene handles, two sets of framebuffers), as the headline does: for a rank's share of a
-    # frame the overlap of consecutive calls is worth more than for a whole one
-    sc2 = tracern.BoxScene(n)
-    fb2 = torch.empty((frames, own * fmt.pitch), dtype=torch.uint8, device="cuda")
-    st2 = torch.cuda.Stream()
-    opts2 = _lib.NtRenderOpts()
-    C.memmove(C.byref(opts2), C.byref(opts), C.sizeof(opts))
-    opts2.overlapped = 1
-    calls = [(sc._handle, C.c_void_p(fb.data_ptr()), own * fmt.pitch, frames, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts2),
-              C.c_void_p(st.cuda_stream)),
-             (sc2._handle, C.c_void_p(fb2.data_ptr()), own * fmt.pitch, frames, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(fst), C.byref(opts2),
-              C.c_void_p(st2.cuda_stream))]
-    state = {"k": 0}
-
-    def go2():
-        _lib.check(L.nt_render_frames_device(*calls[state["k"] & 1]))
-        state["k"] += 1
-    for _ in range(2 * warmup):
-        go2()
-    settle(torch, go2, SETTLE_MS)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        go2()
-    barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    two_ms = float(el.item()) * 1e3 / steps
-    del fb2
+    def leg(fn, calls):
+        """EXACTLY `steps` steps between two barriers after warm-up and settling; MAX over ranks; ms per step."""
+        def go():
+            _lib.check(fn(*calls[state["k"] % len(calls)]))
+            state["k"] += 1
+        for _ in range(warmup * len(calls)):
+            go()
+        settle(torch, go, SETTLE_MS)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            go()
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()) * 1e3 / steps
+    one_ms = leg(L.nt_render_table_device, [table_call(0, opts)])
+    # ... and alternately on two streams (two scene handles, two sets of framebuffers, nt_render_opts.overlapped), as the headline does
+    two_ms = leg(L.nt_render_table_device, [table_call(0, opts2), table_call(1, opts2)])
+    # ... and with the cameras as host arrays on every call (the PCIe-inclusive way; never `value`)
+    host_ms = leg(L.nt_render_frames_device, [host_call(0, opts)])
+    host_two_ms = leg(L.nt_render_frames_device, [host_call(0, opts2), host_call(1, opts2)])
     two_wins = world > 1 and two_ms < one_ms
-    if two_wins:
-        wall = two_ms * 1e-3 * steps
+    ms = two_ms if two_wins else one_ms
+    # leave fb holding the frames of a one-stream call (the gather below looks at the last one)
+    _lib.check(L.nt_render_table_device(*table_call(0, opts)))
+    torch.cuda.synchronize()
     ok = None
     gather_ms = None
     if dist is not None:
@@ -777,12 +716,17 @@ def config5(torch, dist, ntracer_amd, tracern, _lib, ntd, rank, world, local_ran
                                                  a[frames - 1:].ctypes.data_as(_lib.f32p), C.byref(fst), None, C.c_void_p(st.cuda_stream)))
             torch.cuda.synchronize()
             ok = bool(torch.equal(whole.reshape(H, fmt.pitch), full))
-    rays = float(W) * H * frames * steps
-    return {"workload": "BoxScene(10) 4096x4096 RGBX8, %d cameras of the rotation per call (configs[4])" % frames, "value": round(rays / wall / 1e6, 1),
-            "unit": "Mrays/s", "n_gpus": world, "ms_per_step": round(wall * 1e3 / steps, 4), "steps": steps, "frames_per_step": frames,
+    torch.cuda.synchronize()
+    L.nt_camera_table_destroy(C.c_void_p(tab))
+    rays = float(W) * H * frames
+    return {"workload": "BoxScene(10) 4096x4096 RGBX8, %d cameras of the rotation per call (configs[4]), cameras resident in device memory" % frames,
+            "value": round(rays / (ms * 1e-3) / 1e6, 1),
+            "unit": "Mrays/s", "n_gpus": world, "ms_per_step": round(ms, 4), "steps": steps, "frames_per_step": frames,
             "tiling": ("%d-row bands round-robin over ranks" % band_rows) if world > 1 else "single GPU", "scaling": "strong",
             "issue": "steps alternate between two streams" if two_wins else "one stream", "one_stream_ms_per_step": round(one_ms, 4),
             "two_streams_ms_per_step": round(two_ms, 4),
+            "host_cameras": {"one_stream_ms_per_step": round(host_ms, 4), "two_streams_ms_per_step": round(host_two_ms, 4),
+                             "value": round(rays / (host_ms * 1e-3) / 1e6, 1)},
             "gather_ms_per_frame": None if gather_ms is None else round(gather_ms, 3), "gather_verified_equal_to_whole_frame": ok}
 
 
