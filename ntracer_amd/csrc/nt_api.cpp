@@ -570,6 +570,7 @@ struct FrameJob {
     size_t frame_stride;
     int nframes;
     const float *cam_buf;     // device [nframes][4][n] or nullptr
+    const float *cam_dots = nullptr;   // with cam_buf: device [nframes][4], the cameras' dot products (camera_dots)
     hipStream_t stream;
     bool stats;
     bool strict = false;      // nt_render_opts.strict_reference
@@ -662,6 +663,7 @@ int enqueue(nt_scene *s, DeviceState *ds, const FrameJob &job_in) {
     }
     NtCamera cam;
     cam.buf = job.cam_buf;
+    cam.dots = job.cam_dots;
     cam.n = s->n;
     if (!job.cam_buf) pack_camera(s->n, s->origin.data(), s->axes.data(), cam.inl);
     camera_dots(s->n, s->origin.data(), s->axes.data(), cam.odots);
@@ -1281,6 +1283,7 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     job.frame_stride = frame_stride;
     job.nframes = nframes;
     job.cam_buf = (const float *)ds->cams.p;
+    job.cam_dots = job.cam_buf + (size_t)nframes * 4 * s->n;
     job.stream = (hipStream_t)hip_stream;
     job.stats = stats;
     job.strict = opts && opts->strict_reference;
@@ -1335,9 +1338,7 @@ int nt_render_table_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, c
                            const nt_image_format *fmt, const nt_render_opts *opts, void *hip_stream) {
     if (!s || !dest_dev || !table) return fail(NT_E_INVALID, "NULL argument");
     if (table->n != s->n) return fail(NT_E_INVALID, "the camera table is for %d dimensions, the scene has %d", table->n, s->n);
-    // (the dot products of all the table's frames lie behind its last camera, where the kernels look for them by the launch's
-    // frame count: a launch covers the whole table)
-    if (first != 0 || count != table->nframes) return fail(NT_E_UNSUPPORTED, "a launch renders the whole table: first must be 0 and count its frame count");
+    if (first < 0 || count < 1 || first > table->nframes - count) return fail(NT_E_INVALID, "frames %d..%d are not in a table of %d", first, first + count - 1, table->nframes);
     Format f;
     if (int r = parse_format(fmt, f)) return r;
     Bands b;
@@ -1362,7 +1363,8 @@ int nt_render_table_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, c
     job.dest_dev = dest_dev;
     job.frame_stride = frame_stride;
     job.nframes = count;
-    job.cam_buf = table->dev;
+    job.cam_buf = table->dev + (size_t)first * 4 * table->n;                                  // (the table: all cameras, then all dot products)
+    job.cam_dots = table->dev + (size_t)table->nframes * 4 * table->n + (size_t)first * 4;
     job.stream = (hipStream_t)hip_stream;
     job.stats = stats;
     job.strict = opts && opts->strict_reference;

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void box_kernel(NtCameraFixed cam, NtTarget tg
     margin = NT_BOX_MARGIN * (1.0f + margin);
     float dots[4];
     if (cam.buf) {
-        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        const float *dp = cam.dots + (size_t)blockIdx.z * 4;
         dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
     } else {
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void box_redo_kernel(NtCameraFixed cam, NtTarg
     margin = NT_BOX_MARGIN * (1.0f + margin);
     float dots[4];
     if (cam.buf) {
-        const float *dp = cam.buf + (size_t)gridDim.z * 4 * N + (size_t)blockIdx.z * 4;
+        const float *dp = cam.dots + (size_t)blockIdx.z * 4;
         dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
     } else {
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
     margin = NT_BOX_MARGIN * (1.0f + margin);
     float dots[4];
     if (cam.buf) {
-        const float *dp = cam.buf + (size_t)nframes * 4 * N + (size_t)frame * 4;
+        const float *dp = cam.dots + (size_t)frame * 4;
         dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
     } else {
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
@@ -1397,6 +1397,7 @@ template <int N>
 int launch_box_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtTarget &tg_in) {
     NtCameraFixed cf;
     cf.buf = cam.buf;
+    cf.dots = cam.dots;
     for (int k = 0; k < 4; ++k) cf.odots[k] = cam.odots[k];
     cf.n = N;
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];

@@ -2181,6 +2181,7 @@ template <int N>
 int launch_composite_fixed(const NtLaunchInfo &li, const NtCamera &cam, const NtCompositeDev &sc, const NtTarget &tg) {
     NtCameraFixed cf;
     cf.buf = cam.buf;
+    cf.dots = cam.dots;
     for (int k = 0; k < 4; ++k) cf.odots[k] = cam.odots[k];
     cf.n = N;
     for (int k = 0; k < 4 * N; ++k) cf.inl[k] = cam.inl[k];

@@ -91,13 +91,15 @@ struct NtTarget {
 // not part of the exact predicate): |origin|^2, origin.right, origin.up, origin.forward -- `odots` for the inline
 // camera, four floats per frame after the last camera of a table.
 struct NtCamera {
-    const float *buf;         // nullptr => use `inl`; else [nframes][4][n] followed by [nframes][4] dot products
+    const float *buf;         // nullptr => use `inl`; else [nframes][4][n] cameras of the launch's frames
+    const float *dots;        // with buf: [nframes][4] dot products of the same frames (|o|^2, o.right, o.up, o.forward)
     int n;
     float odots[4];
     float inl[4 * NT_DEV_MAX_DIM];
 };
 struct NtCameraFixed {        // N <= 8: 4*8 floats inline
     const float *buf;
+    const float *dots;
     int n;
     float odots[4];
     float inl[4 * NT_DEV_MAX_FIXED_BOX];

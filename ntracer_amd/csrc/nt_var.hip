@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void box_kernel_var(NtCamera cam, NtTarget tg)
     // division and the n-1 checks.  Waves that cannot hit normalise dir[0] only.
     float dots[4];
     if (cam.buf) {
-        const float *dp = cam.buf + (size_t)gridDim.z * 4 * n + (size_t)blockIdx.z * 4;
+        const float *dp = cam.dots + (size_t)blockIdx.z * 4;
         dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
     } else {
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void box_rows_kernel_var(NtCamera cam, NtTarge
     const float maxv = (float)tg.plain_maxval;
     float dots[4];
     if (cam.buf) {
-        const float *dp = cam.buf + (size_t)gridDim.z * 4 * n + (size_t)blockIdx.z * 4;
+        const float *dp = cam.dots + (size_t)blockIdx.z * 4;
         dots[0] = dp[0]; dots[1] = dp[1]; dots[2] = dp[2]; dots[3] = dp[3];
     } else {
         dots[0] = cam.odots[0]; dots[1] = cam.odots[1]; dots[2] = cam.odots[2]; dots[3] = cam.odots[3];

@@ -445,7 +445,7 @@ class CameraTable(object):
                 pass
 
     def render(self, scene, dest, format, frame_bytes=None, band_rank=0, band_world=1, compact=False, band_rows=0, strict_reference=None,
-               overlapped=False):
+               overlapped=False, first=0, count=None):
         """``overlapped``: the caller keeps two or more torch streams busy with calls like this one (nt_render_opts.overlapped:
         the launches are shaped for throughput rather than for the time of a call that runs alone; same pixels)."""
         dev = _device_pointer(dest)
@@ -454,9 +454,11 @@ class CameraTable(object):
         ptr, nbytes, index, stream = dev
         fmt = format._as_struct()
         opts = _opts(index, band_rank, band_world, compact, False, band_rows=band_rows, strict_reference=strict_reference, overlapped=overlapped)
+        if count is None:
+            count = self.frames - first                 # (frames [first, first + count) of the table go to dest's frames 0 .. count-1)
         if frame_bytes is None:
-            frame_bytes = nbytes // self.frames
-        _lib.check(_lib.lib().nt_render_table_device(scene._handle, C.c_void_p(ptr), frame_bytes, self._h, 0, self.frames, C.byref(fmt),
+            frame_bytes = nbytes // max(count, 1)
+        _lib.check(_lib.lib().nt_render_table_device(scene._handle, C.c_void_p(ptr), frame_bytes, self._h, int(first), int(count), C.byref(fmt),
                                                      C.byref(opts), C.c_void_p(stream)))
         return True
 

@@ -1358,7 +1358,7 @@ def test_box_soak_slice(n):
 def test_camera_table_renders_the_same_frames():
     """nt_camera_table_create / nt_render_table_device (cameras of a path resident in device memory, one launch a call) against
     nt_render_frames_device (cameras packed and uploaded per call): the same bytes, for BoxScene -- whole frames and one
-    rank's bands -- and for the 120-cell's packet kernel; and the refusals (wrong dimension, part of a table)."""
+    rank's bands -- and for the 120-cell's packet kernel; parts of a table; and the refusals (wrong dimension, frames outside the table)."""
     import torch
     from ntracer_amd.render import CameraTable
     g = fx.load("box_n6_1920x1080")
@@ -1390,8 +1390,28 @@ def test_camera_table_renders_the_same_frames():
     assert np.array_equal(full[5].cpu().numpy().reshape(1080, fmt.pitch), ref)
     with pytest.raises(ValueError, match="dimensions"):
         tab.render(tracern.BoxScene(5), full, fmt)
-    with pytest.raises(NotImplementedError):
-        _lib.check(_lib.lib().nt_render_table_device(sc._handle, C.c_void_p(full.data_ptr()), 1080 * fmt.pitch, tab._h, 2, 4, C.byref(fst), None, C.c_void_p(st)))
+    # part of a table: frames [first, first + count) -- also of BoxScene(10), whose second kernel reads the cameras too
+    part = torch.zeros((4, 1080 * fmt.pitch), dtype=torch.uint8, device="cuda")
+    assert tab.render(sc, part, fmt, first=2, count=4)
+    torch.cuda.synchronize()
+    assert torch.equal(part, full[2:6])
+    for first, count in ((-1, 2), (F - 1, 2), (0, 0), (0, F + 1)):
+        with pytest.raises(ValueError):
+            _lib.check(_lib.lib().nt_render_table_device(sc._handle, C.c_void_p(full.data_ptr()), 1080 * fmt.pitch, tab._h, first, count, C.byref(fst), None,
+                                                         C.c_void_p(st)))
+    g10 = fx.load("box_n10_4096x4096")
+    o10 = np.ascontiguousarray(g10["origins"][[5, 60, 61, 130, 140]], np.float32)
+    a10 = np.ascontiguousarray(g10["axes"][[5, 60, 61, 130, 140]], np.float32)
+    sc10 = tracern.BoxScene(10)
+    fmt10 = fmt_of(1024, 640, fx.RGBX8)
+    tab10 = CameraTable(10, o10, a10)
+    whole10 = torch.zeros((5, 640 * fmt10.pitch), dtype=torch.uint8, device="cuda")
+    part10 = torch.zeros((2, 640 * fmt10.pitch), dtype=torch.uint8, device="cuda")
+    tab10.render(sc10, whole10, fmt10)
+    tab10.render(sc10, part10, fmt10, first=3, count=2)
+    torch.cuda.synchronize()
+    assert torch.equal(part10, whole10[3:5])
+    assert np.array_equal(part10[0].cpu().numpy().reshape(640, fmt10.pitch), ob.OracleScene(10, o10[3], a10[3]).render(1024, 640, fx.RGBX8, threads=8))
     g4 = fx.load("cell120_n4")
     sc4 = tracern.CompositeScene.from_flat(4, fx.flat_of(g4))
     o4 = np.ascontiguousarray(g4["origins"][[0, 40, 93]], np.float32)
