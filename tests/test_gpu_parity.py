@@ -10,6 +10,8 @@ against the reference (whose -ffast-math build differs in the last bits).  Packe
 exactly.
 """
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -1310,6 +1312,24 @@ def test_shadow_rays_are_counted():
     render_host(sc, fmt_of(96, 64, fx.RGBX8), collect_stats=True)
     st = sc.last_stats()
     assert st["shadow_rays"] > 0 and st["rays"] > 96 * 64      # primary + reflection
+
+
+@pytest.mark.parametrize("name", ["cell120_n4", "orthoplex5_n5", "simplex10_n10", "feature5_n5", "lit12_n12", "feature16_n16"])
+def test_composite_soak_slice(name):
+    """A slice of tools/composite_soak.py in the suite: a golden scene as captured, lit with shadows (one light outside the scene's
+    box, one inside it -- the shadow walk's far-child rule both ways -- and a global one) and with every material 30 % reflective,
+    four random cameras each, through the drop-in call against the oracle's frames: colours within 1e-5, and the cameras do see
+    the scene.  The fixed-n packet and shading kernels (n = 4, 5, 10), the transparency kernels, and the run-time-n ones (12, 16)."""
+    import bench
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import composite_soak
+    threads = max(1, min(64, bench.cpu_quota_cores() - 1))
+    res = composite_soak.soak_scene(name, 4, 991, 240, 150, threads)
+    assert [r[0] for r in res] == ["captured", "lit", "mirror"]
+    for vname, n, worst, nbad, frames_bad, hits, shadow in res:
+        assert nbad == 0 and worst < TOL_ORACLE, (name, vname, worst, nbad)
+        assert hits > 0.003 * 4 * 240 * 150, (name, vname, hits)
+        assert (shadow > 0) == (vname != "captured" or name in ("feature5_n5", "lit12_n12", "feature16_n16")), (name, vname, shadow)
 
 
 @pytest.mark.parametrize("n", [3, 6, 8, 10, 19])

@@ -34,66 +34,74 @@ def cameras(rng, n, dist, count):
     return out
 
 
+def soak_scene(name, per, seed, W, H, threads):
+    """The three variants of one golden scene under `per` random cameras each: [(variant, n, worst |diff|, values beyond TOL,
+    frames with such values, primary hits, shadow rays)]."""
+    fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(*c) for c in RGBF32])
+    g = fx.load(name)
+    n = int(g["dimension"])
+    base = fx.params_of(g)
+    dist = abs(float(g["cam_distance"])) if "cam_distance" in g.files else float(np.linalg.norm(g["origins"][0]))
+    lo, hi = np.asarray(g["aabb_start"], np.float32), np.asarray(g["aabb_end"], np.float32)
+    ctr, ext = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    variants = [("captured", fx.flat_of(g), dict(base))]
+    lit = dict(base)
+    out_pos = ctr + ext * 3.0 * np.resize(np.array([1.0, 0.8, -0.9, 0.4], np.float32), n)
+    in_pos = ctr + ext * 0.15 * np.resize(np.array([-0.5, 0.3, 0.2, -0.4], np.float32), n)
+    gdir = np.resize(np.array([0.2, -0.9, 0.3, 0.1], np.float32), n)
+    lit.update(shadows=1, point_light_pos=[list(map(float, out_pos)), list(map(float, in_pos))],
+               point_light_color=[[float(40.0 * np.linalg.norm(ext) ** (n - 1))] * 3, [float(0.5 * np.linalg.norm(ext) ** (n - 1))] * 3],
+               global_light_dir=[list(map(float, gdir / np.linalg.norm(gdir)))], global_light_color=[[0.4, 0.4, 0.5]], ambient=[0.02, 0.02, 0.03])
+    flat_plain = fx.flat_of(g)
+    m = np.array(flat_plain["materials"], np.float32).copy()
+    m[:, 7] = 0.0
+    flat_plain["materials"] = m
+    variants.append(("lit", flat_plain, lit))
+    flat_mirror = fx.flat_of(g)
+    m = np.array(flat_mirror["materials"], np.float32).copy()
+    m[:, 7] = 0.3
+    flat_mirror["materials"] = m
+    mir = dict(lit)
+    mir.update(max_reflect_depth=2)
+    variants.append(("mirror", flat_mirror, mir))
+    out = []
+    for vname, flat, params in variants:
+        rng = np.random.default_rng(seed + n * 131 + len(vname))
+        cams = cameras(rng, n, dist, per)
+        sc = tracern.CompositeScene.from_flat(n, flat)
+        sc.set_params_flat(params)
+        osc = ob.OracleScene(n, cams[0][0], cams[0][1], flat=flat, params=params)
+        worst, nbad, frames_bad, hits, shadow = 0.0, 0, 0, 0, 0
+        for o, a in cams:
+            sc._set_camera_arrays(o, a)
+            buf = bytearray(fmt.pitch * H)
+            assert ntracer_amd.BlockingRenderer().render(buf, fmt, sc)
+            got = np.frombuffer(bytes(buf), np.uint8).reshape(H, fmt.pitch).view(">f4")
+            osc.set_camera(o, a)
+            ref, cnt = osc.render(W, H, RGBF32, threads=threads, counters=True)
+            ref = ref.view(">f4")
+            hits += cnt.get("hits", 0)
+            shadow += cnt.get("shadow_rays", 0)
+            d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+            worst = max(worst, float(d.max()))
+            k = int((d > TOL).sum())
+            nbad += k
+            frames_bad += 1 if k else 0
+        out.append((vname, n, worst, nbad, frames_bad, hits, shadow))
+    return out
+
+
 def main():
     per = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 4100
     W, H = (int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "320x200").split("x"))
     names = sys.argv[4].split(",") if len(sys.argv) > 4 else ["cell120_n4", "cell600_n4", "orthoplex5_n5", "simplex7_n7", "simplex9_n9", "simplex10_n10",
                                                               "feature5_n5", "feature11_n11", "lit12_n12", "feature16_n16"]
-    sys.path.insert(0, ROOT)
     import bench
     threads = max(1, min(64, bench.cpu_quota_cores() - 1))
-    fmt = ntracer_amd.ImageFormat(W, H, [ntracer_amd.Channel(*c) for c in RGBF32])
     bad_total = 0
     for name in names:
-        g = fx.load(name)
-        n = int(g["dimension"])
-        base = fx.params_of(g)
-        dist = abs(float(g["cam_distance"])) if "cam_distance" in g.files else float(np.linalg.norm(g["origins"][0]))
-        lo, hi = np.asarray(g["aabb_start"], np.float32), np.asarray(g["aabb_end"], np.float32)
-        ctr, ext = 0.5 * (lo + hi), 0.5 * (hi - lo)
-        variants = [("captured", fx.flat_of(g), dict(base))]
-        lit = dict(base)
-        out_pos = ctr + ext * 3.0 * np.resize(np.array([1.0, 0.8, -0.9, 0.4], np.float32), n)
-        in_pos = ctr + ext * 0.15 * np.resize(np.array([-0.5, 0.3, 0.2, -0.4], np.float32), n)
-        lit.update(shadows=1, point_light_pos=[list(map(float, out_pos)), list(map(float, in_pos))],
-                   point_light_color=[[float(40.0 * np.linalg.norm(ext) ** (n - 1))] * 3, [float(0.5 * np.linalg.norm(ext) ** (n - 1))] * 3],
-                   global_light_dir=[list(map(float, np.resize(np.array([0.2, -0.9, 0.3, 0.1], np.float32), n) / np.linalg.norm(np.resize(np.array([0.2, -0.9, 0.3, 0.1], np.float32), n))))],
-                   global_light_color=[[0.4, 0.4, 0.5]], ambient=[0.02, 0.02, 0.03])
-        flat_plain = fx.flat_of(g)
-        m = np.array(flat_plain["materials"], np.float32).copy()
-        m[:, 7] = 0.0
-        flat_plain["materials"] = m
-        variants.append(("lit", flat_plain, lit))
-        flat_mirror = fx.flat_of(g)
-        m = np.array(flat_mirror["materials"], np.float32).copy()
-        m[:, 7] = 0.3
-        flat_mirror["materials"] = m
-        mir = dict(lit)
-        mir.update(max_reflect_depth=2)
-        variants.append(("mirror", flat_mirror, mir))
-        for vname, flat, params in variants:
-            rng = np.random.default_rng(seed + n * 131 + len(vname))
-            cams = cameras(rng, n, dist, per)
-            sc = tracern.CompositeScene.from_flat(n, flat)
-            sc.set_params_flat(params)
-            osc = ob.OracleScene(n, cams[0][0], cams[0][1], flat=flat, params=params)
-            worst, nbad, frames_bad, hits, shadow = 0.0, 0, 0, 0, 0
-            for o, a in cams:
-                sc._set_camera_arrays(o, a)
-                buf = bytearray(fmt.pitch * H)
-                assert ntracer_amd.BlockingRenderer().render(buf, fmt, sc)
-                got = np.frombuffer(bytes(buf), np.uint8).reshape(H, fmt.pitch).view(">f4")
-                osc.set_camera(o, a)
-                ref, cnt = osc.render(W, H, RGBF32, threads=threads, counters=True)
-                ref = ref.view(">f4")
-                hits += cnt.get("hits", 0)
-                shadow += cnt.get("shadow_rays", 0)
-                d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-                worst = max(worst, float(d.max()))
-                k = int((d > TOL).sum())
-                nbad += k
-                frames_bad += 1 if k else 0
+        for vname, n, worst, nbad, frames_bad, hits, shadow in soak_scene(name, per, seed, W, H, threads):
             print("%-14s %-8s n=%-2d %3d frames %dx%d (%4.1f %% of the primary rays hit, %d shadow rays): worst |diff| %.2e, %d values beyond %.0e in %d frames"
                   % (name, vname, n, per, W, H, 100.0 * hits / (per * W * H), shadow, worst, nbad, TOL, frames_bad), flush=True)
             bad_total += nbad
