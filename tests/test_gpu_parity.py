@@ -1318,14 +1318,14 @@ def test_shadow_rays_are_counted():
 def test_composite_soak_slice(name):
     """A slice of tools/composite_soak.py in the suite: a golden scene as captured, lit with shadows (one light outside the scene's
     box, one inside it -- the shadow walk's far-child rule both ways -- and a global one) and with every material 30 % reflective,
-    four random cameras each, through the drop-in call against the oracle's frames: colours within 1e-5, and the cameras do see
+    and lit under the native builder's k-d tree, four random cameras each, through the drop-in call against the oracle's frames: colours within 1e-5, and the cameras do see
     the scene.  The fixed-n packet and shading kernels (n = 4, 5, 10), the transparency kernels, and the run-time-n ones (12, 16)."""
     import bench
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import composite_soak
     threads = max(1, min(64, bench.cpu_quota_cores() - 1))
     res = composite_soak.soak_scene(name, 4, 991, 240, 150, threads)
-    assert [r[0] for r in res] == ["captured", "lit", "mirror"]
+    assert [r[0] for r in res] == ["captured", "lit", "mirror", "rebuilt"]
     for vname, n, worst, nbad, frames_bad, hits, shadow in res:
         assert nbad == 0 and worst < TOL_ORACLE, (name, vname, worst, nbad)
         assert hits > 0.003 * 4 * 240 * 150, (name, vname, hits)

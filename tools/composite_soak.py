@@ -2,7 +2,7 @@
 """Composite-scene soak (development aid): the golden scenes under random cameras, every frame rendered through the drop-in call
 (BlockingRenderer.render, three fp32 channels) and compared with the oracle's frame, colour by colour.
     python3 tools/composite_soak.py [frames_per_scene [seed [WxH [scenes]]]]
-Variants per scene: as captured; "lit" -- a point light outside and one inside the scene's box, a global light, shadows on,
+Variants per scene: as captured; "rebuilt" -- the lit scene under the native builder's k-d tree; "lit" -- a point light outside and one inside the scene's box, a global light, shadows on,
 nothing reflective (the per-lane shadow walk with its far-child rule); "mirror" -- every material 30 % reflective, depth 2.
 Prints one line per (scene, variant): frames, worst |difference|, pixels beyond 1e-5."""
 import os
@@ -64,6 +64,10 @@ def soak_scene(name, per, seed, W, H, threads):
     mir = dict(lit)
     mir.update(max_reflect_depth=2)
     variants.append(("mirror", flat_mirror, mir))
+    # the same primitives, lit, under the k-d tree of the native builder (with shadows on the pixels depend on the tree, here as
+    # in the reference: the oracle walks the same rebuilt tree)
+    reb = tracern.CompositeScene.from_flat(n, flat_plain).with_rebuilt_tree()
+    variants.append(("rebuilt", dict(reb._flat), lit))
     out = []
     for vname, flat, params in variants:
         rng = np.random.default_rng(seed + n * 131 + len(vname))
