@@ -49,18 +49,30 @@ def main():
         o = np.ascontiguousarray(np.stack(origins), np.float32)
         a = np.ascontiguousarray(np.stack(axes), np.float32)
         sc = tracern.BoxScene(n)
-        fb = torch.zeros((per_dim, h * fmt.pitch), dtype=torch.uint8, device="cuda")
-        _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), h * fmt.pitch, per_dim,
-                                                      o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(st), None,
+        # BANDS=world,rank,band_rows: one rank's share of the frames (compact buffer); OVERLAPPED=1: in the launch shape of callers
+        # that overlap their calls (nt_render_opts.overlapped)
+        own = np.arange(h)
+        opts = None
+        if os.environ.get("BANDS") or os.environ.get("OVERLAPPED"):
+            from ntracer_amd import distributed as ntd
+            world, rank, brows = (int(v) for v in os.environ.get("BANDS", "1,0,32").split(","))
+            opts = _lib.NtRenderOpts()
+            opts.device = -1
+            opts.band_rank, opts.band_world, opts.band_rows, opts.compact = rank, world, brows, 1
+            opts.overlapped = int(os.environ.get("OVERLAPPED", "0"))
+            own = ntd.owned_rows(h, rank, world, brows)
+        fb = torch.zeros((per_dim, len(own) * fmt.pitch), dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), len(own) * fmt.pitch, per_dim,
+                                                      o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p), C.byref(st), C.byref(opts) if opts is not None else None,
                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         torch.cuda.synchronize()
-        got = fb.cpu().numpy().reshape(per_dim, h, fmt.pitch)
+        got = fb.cpu().numpy().reshape(per_dim, len(own), fmt.pitch)
         osc = ob.OracleScene(n, o[0], a[0])
         nbad = 0
         for f in range(per_dim):
             osc.set_camera(o[f], a[f])
             ref = osc.render(w, h, RGBX_, threads=threads)
-            d = int((got[f] != ref).sum())
+            d = int((got[f] != ref[own]).sum())
             if d:
                 nbad += 1
                 print("n=%d frame %d: %d bytes differ" % (n, f, d))
