@@ -478,7 +478,7 @@ class BlockingRenderer(object):
         self._busy = False
 
     def render(self, dest, format, scene, band_rank=0, band_world=1, compact=False, collect_stats=False, strict_reference=None,
-               band_rows=0):
+               band_rows=0, overlapped=False):
         if not isinstance(format, ImageFormat):
             raise TypeError("format must be an ImageFormat")
         if not isinstance(scene, Scene):
@@ -494,7 +494,9 @@ class BlockingRenderer(object):
             L = _lib.lib()
             if dev is not None:
                 ptr, nbytes, index, stream = dev
-                opts = _opts(index, band_rank, band_world, compact, collect_stats, band_rows=band_rows, strict_reference=strict_reference)
+                # (overlapped: device destinations only -- the caller keeps several torch streams busy, nt_render_opts.overlapped)
+                opts = _opts(index, band_rank, band_world, compact, collect_stats, band_rows=band_rows, strict_reference=strict_reference,
+                             overlapped=overlapped)
                 _lib.check(L.nt_render_device(scene._handle, C.c_void_p(ptr), nbytes, C.byref(fmt), C.byref(opts),
                                               C.c_void_p(stream)))
                 return True
