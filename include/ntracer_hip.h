@@ -229,7 +229,9 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
    has 160) packed and uploaded ONCE; nt_render_table_device then renders frames [first, first + count) of it exactly like
    nt_render_frames_device, but with nothing to pack or upload per call -- one kernel launch instead of two, which is what a
    render loop over a fixed path, and a rank's small share of a tiled frame, spend a tenth of their time on.
-   The table belongs to the scene's dimension and to one device; it may be used by any scene of that dimension. */
+   The table belongs to the scene's dimension and to one device; it may be used by any scene of that dimension.
+   After a warm-up call such a call only launches kernels and may be captured into a HIP graph; nt_render_frames_device, which
+   stages host memory per call, returns NT_E_UNSUPPORTED on a capturing stream. */
 typedef struct nt_camera_table nt_camera_table_t;
 nt_camera_table_t *nt_camera_table_create(int dimension, int nframes, const float *origins, const float *axes, int device);
 void nt_camera_table_destroy(nt_camera_table_t *t);

@@ -1243,6 +1243,14 @@ int nt_render_frames_device(nt_scene_t *s, void *dest_dev, size_t frame_stride, 
     DeviceState *ds;
     if (int r = device_state(s, dev, ds)) return r;
     if (int r = upload_scene(s, ds)) return r;
+    {
+        // This entry point stages the caller's host arrays in a pinned slot that later calls reuse: a graph would replay the
+        // launch, not the staging.  Refused while `hip_stream` is being captured -- a camera table (nt_render_table_device), whose
+        // cameras live in device memory, is what a graph wants (tests: test_render_calls_captured_in_a_hip_graph).
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)hip_stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(NT_E_UNSUPPORTED, "nt_render_frames_device stages host cameras per call and cannot be captured into a graph: use a camera table");
+    }
     if (int r = use_stream(ds, (hipStream_t)hip_stream)) return r;
     const int n = s->n;
     const size_t cam_floats = (size_t)nframes * 4 * n + (size_t)nframes * 4;

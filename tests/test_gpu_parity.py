@@ -1481,6 +1481,52 @@ def test_box_kernel_paths_alternate_on_one_scene(monkeypatch):
                 assert np.array_equal(got[k], refs[k]), (n, path, il, k, int((got[k] != refs[k]).sum()))
 
 
+def test_render_calls_captured_in_a_hip_graph():
+    """After one warm-up call on the capture stream (scratch allocated, row table cached, no change of stream to drain) a
+    render call from a camera table is nothing but kernel launches and can be captured into a HIP graph (torch.cuda.graph)
+    and replayed: BoxScene(6) (one kernel a call) and BoxScene(10) (tile kernel + second kernel) -- the replay's bytes are the
+    direct call's.  nt_render_frames_device, which stages the caller's host cameras on every call, refuses to be captured."""
+    import torch
+    from ntracer_amd.render import CameraTable
+    s = torch.cuda.Stream()
+    L = _lib.lib()
+    for n, name, W, H in ((6, "box_n6_1920x1080", 1920, 1080), (10, "box_n10_4096x4096", 1024, 640)):
+        g = fx.load(name)
+        F = 6
+        o = np.ascontiguousarray(g["origins"][20:20 + F], np.float32)
+        a = np.ascontiguousarray(g["axes"][20:20 + F], np.float32)
+        fmt = fmt_of(W, H, fx.RGBX8)
+        fst = fmt._as_struct()
+        sc = tracern.BoxScene(n)
+        tab = CameraTable(n, o, a)
+        ref = torch.zeros((F, H * fmt.pitch), dtype=torch.uint8, device="cuda")
+        fb = torch.zeros_like(ref)
+
+        def call(buf):
+            return L.nt_render_table_device(sc._handle, C.c_void_p(buf.data_ptr()), H * fmt.pitch, tab._h, 0, F, C.byref(fst), None, C.c_void_p(s.cuda_stream))
+        with torch.cuda.stream(s):
+            _lib.check(call(ref))
+        s.synchronize()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        refused = None
+        with torch.cuda.graph(gr, stream=s):
+            _lib.check(call(fb))
+            _lib.check(call(fb))
+            if n == 6:
+                refused = L.nt_render_frames_device(sc._handle, C.c_void_p(fb.data_ptr()), H * fmt.pitch, F, o.ctypes.data_as(_lib.f32p), a.ctypes.data_as(_lib.f32p),
+                                                    C.byref(fst), None, C.c_void_p(s.cuda_stream))
+        assert refused is None or refused == _lib.NT_E_UNSUPPORTED
+        for rep in range(2):
+            fb.zero_()
+            torch.cuda.synchronize()
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(fb, ref), (n, rep)
+        del gr
+        assert np.array_equal(ref[2].cpu().numpy().reshape(H, fmt.pitch), ob.OracleScene(n, o[2], a[2]).render(W, H, fx.RGBX8, threads=8))
+
+
 def test_overlapped_hint_changes_the_launch_shape_not_the_bytes():
     """nt_render_opts.overlapped (the caller keeps several streams busy: long waves from 64 rows up) must never change a pixel:
     a rank's eighth of 160 headline frames -- 136 rows in 8-row bands, the launch whose shape the hint changes -- and the whole
