@@ -7,7 +7,12 @@
 // three instead of two: 204 -> 270, 196 -> 260, 193 -> 249, 192 -> 223 Grays/s.  No gain, not taken: n = 6 at seven waves
 // (72 VGPRs, three dwords spilled: 353.9 vs 353.6 us on the headline), n = 7, 8 at six, n = 16 at four.
 #if defined(NT_INST_N) && !defined(NT_TILE_OCC)
-#if NT_INST_N == 10
+#if NT_INST_N <= 5
+// (up to five dimensions the tile kernel needs 55..70 VGPRs -- seven or eight waves a SIMD -- but its 106 SGPRs admit six:
+// ⌊800 / (⌈sgpr/16⌉·16 + 16)⌋, MI355X_MICROARCH.md "Residency".  With a budget of 96 (94 used, nothing spilled) seven are
+// admitted: BoxScene(3) 1080p, 160 frames 292.7 -> 285.5 us a call; 80 -- eight waves -- measures the same)
+#define NT_TILE_OCC __attribute__((amdgpu_num_sgpr(96)))
+#elif NT_INST_N == 10
 #define NT_TILE_OCC __attribute__((amdgpu_waves_per_eu(5, 5)))
 #elif NT_INST_N == 15
 #define NT_TILE_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
