@@ -980,6 +980,9 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
 #ifndef NT_TILE_OCC
 #define NT_TILE_OCC
 #endif
+#ifndef NT_BOX_PIN_UP
+#define NT_BOX_PIN_UP 1
+#endif
 template <int N, bool F32, int ROWS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCameraFixed cam, NtTarget tg) {
     static_assert(ROWS == 8 || ROWS == 16 || ROWS == 32 || ROWS == 64, "sixteen row codes to a qword, one to four qwords a wave");
@@ -1129,7 +1132,9 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             upv[j] = up[j];
-            asm volatile("" : "+v"(upv[j]));
+            // (NT_BOX_PIN_UP = 0: only up[0], the one the culled rows' loop multiplies -- the others stay in scalar registers and
+            // are moved over where a row needs them, which is what lets the n = 6 kernel fit seven waves' registers unspilled)
+            if (NT_BOX_PIN_UP || j == 0) asm volatile("" : "+v"(upv[j]));
         }
         // packed RGB: the quadratic |dir|^2 = bb - 2 bu sy + uu sy^2 of the guarded rsq quantisation (see box_kernel<N, true>)
         float bb = 0.0f, bu = 0.0f, uu = 0.0f;

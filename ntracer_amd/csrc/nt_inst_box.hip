@@ -12,6 +12,11 @@
 // ⌊800 / (⌈sgpr/16⌉·16 + 16)⌋, MI355X_MICROARCH.md "Residency".  With a budget of 96 (94 used, nothing spilled) seven are
 // admitted: BoxScene(3) 1080p, 160 frames 292.7 -> 285.5 us a call; 80 -- eight waves -- measures the same)
 #define NT_TILE_OCC __attribute__((amdgpu_num_sgpr(96)))
+#elif NT_INST_N == 6
+// (seven waves a SIMD instead of six: 71 VGPRs once up[1..5] are no longer pinned in vector registers, nothing spilled, and the SGPR
+// budget that lets the hardware admit the seventh: headline call 350.8 -> 345.2 us)
+#define NT_TILE_OCC __attribute__((amdgpu_waves_per_eu(7, 7), amdgpu_num_sgpr(96)))
+#define NT_BOX_PIN_UP 0
 #elif NT_INST_N == 10
 #define NT_TILE_OCC __attribute__((amdgpu_waves_per_eu(5, 5)))
 #elif NT_INST_N == 15
