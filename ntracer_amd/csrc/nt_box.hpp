@@ -1134,7 +1134,8 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
             upv[j] = up[j];
             // (NT_BOX_PIN_UP = 0: only up[0], the one the culled rows' loop multiplies -- the others stay in scalar registers and
             // are moved over where a row needs them, which is what lets the n = 6 kernel fit seven waves' registers unspilled)
-            if (NT_BOX_PIN_UP || j == 0) asm volatile("" : "+v"(upv[j]));
+            // (the fp32 kernel, bound by its stores, keeps them pinned: unpinned it executes 8 % more instructions for nothing)
+            if (NT_BOX_PIN_UP || F32 || j == 0) asm volatile("" : "+v"(upv[j]));
         }
         // packed RGB: the quadratic |dir|^2 = bb - 2 bu sy + uu sy^2 of the guarded rsq quantisation (see box_kernel<N, true>)
         float bb = 0.0f, bu = 0.0f, uu = 0.0f;
