@@ -974,9 +974,10 @@ __global__ __launch_bounds__(256) void box_cull_kernel(NtCameraFixed cam, NtTarg
 #else
 #define NT_EXP_STORE_IF
 #endif
-// Occupancy (-DNT_TILE_OCC=...): holding the packed-RGB kernel to 64 VGPRs -- eight waves a SIMD instead of seven at N = 6,
-// `__attribute__((amdgpu_waves_per_eu(8, 8)))` -- was 1 % faster, but the six dwords a lane it spills are 125 MB of scratch
-// traffic a call (HBM bytes 1.16x the framebuffers instead of 1.03x) and 9 % more vector instructions: not taken.
+// Occupancy (-DNT_TILE_OCC=..., set per dimension in nt_inst_box.hip).  The waves a SIMD are decided by BOTH register files:
+// 512 / VGPRs and floor(800 / (ceil(SGPRs / 16) * 16 + 16)) -- with 106 SGPRs that is six, whatever `amdgpu_waves_per_eu` says
+// about the vector registers (round 2 "held the kernel to 64 VGPRs for eight waves" and saw 1 % for six spilled dwords a lane:
+// it was still running six).  Up to n = 6 the kernels are given an SGPR budget of 96, which admits seven.
 #ifndef NT_TILE_OCC
 #define NT_TILE_OCC
 #endif
