@@ -14,10 +14,12 @@ echo "[1] kernel trace of the headline loop (one stream, one kernel at a time: t
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/kt -- python3 $root/bench.py --headline-only > $raw/kt.log 2>&1
 cp $(ls $raw/kt/*/*_kernel_stats.csv | head -1) $out/${tag}_bench_kernel_stats.csv
 grep "^{" $raw/kt.log > $out/${tag}_bench_under_profiler.json
+cp $root/gpurun_out/bench_details.json $out/${tag}_bench_under_profiler_details.json
 echo "[1b] kernel trace of the whole bench (also the two-stream loops, whose kernels overlap and so last longer each; fp32, bands, config 5, extras)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ktall -- $B > $raw/ktall.log 2>&1
 cp $(ls $raw/ktall/*/*_kernel_stats.csv | head -1) $out/${tag}_bench_all_kernel_stats.csv
 grep "^{" $raw/ktall.log > $out/${tag}_bench_all_under_profiler.json
+cp $root/gpurun_out/bench_details.json $out/${tag}_bench_all_under_profiler_details.json
 echo "[2] HBM bytes: WRITE_SIZE and FETCH_SIZE, separate passes"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $raw/w -- $S > $raw/w.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $raw/f -- $S > $raw/f.log 2>&1
