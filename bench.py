@@ -467,7 +467,7 @@ def compact(out):
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
         c["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind"))
-        c["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:110]
+        c["cpu_baseline"]["sample"] = (cb.get("sample") or "").split(" (")[0]          # (without the parenthesis on the thread pool)
         c["cpu_baseline"]["cell120"] = pick(cb.get("cell120"), ("value", "unit", "cores", "kind"))
         pv = cb.get("port_vs_reference")
         if isinstance(pv, dict):
