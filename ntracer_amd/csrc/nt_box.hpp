@@ -1121,6 +1121,9 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
         // (instruction selection works block by block and only recognises base + zero-extended 32-bit offset when it sees the
         // extension: the empty asm keeps it from being hoisted out of the row loops)
 #define NT_LANE_OFF() ({ asm volatile("" : "+v"(xoff)); xoff; })
+        // mask &= ~(1 << bit) as ONE scalar instruction (the compiler writes mask & (mask - 1) as an add and an and): the lean loops
+        // run about as many scalar instructions a row as vector ones
+#define NT_CLEAR_BIT(mask, bit) asm("s_bitset0_b32 %0, %1" : "+s"(mask) : "s"(bit))
         int x = (int)blockIdx.x * 64 + lane;
         x = x < tg.width ? x : tg.width - 1;
         uint32_t xoff = (uint32_t)x * (uint32_t)tg.bpp;
@@ -1207,7 +1210,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
             constexpr bool SEL8 = decltype(sel8)::value;
             while (quick != 0u) {
                 const int rr = __builtin_ctz(quick);
-                quick &= quick - 1u;
+                NT_CLEAR_BIT(quick, rr);
                 NT_ROW_LOAD(rr);
                 const float d0 = base[0] - upv[0] * sy;                   // dir[0], bit for bit
                 const float sqa = fmaf(sy, fmaf(sy, uu, m2bu), bb);
@@ -1222,15 +1225,11 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
                     // 8-bit fields: t + 2^23 has round(t) in its low mantissa byte (t < 255.5; the guard keeps t off the
                     // half-way points, so nearest-even is the reference's rounding), which is the byte v_perm_b32 picks
                     const uint32_t q = __float_as_uint(t + 8388608.0f);
-                    // (the sign of dir[0] rarely changes within a stretch: the select is skipped when it is + throughout)
-                    uint32_t w;
-                    if (__builtin_amdgcn_ballot_w64(!(d0 > 0.0f)) != 0ull) {
-                        w = __builtin_amdgcn_perm(d0 > 0.0f ? q : 0u, q, tg.plain_sel);
-                        asm volatile("" : "+v"(w));                 // (keeps this a branch, and the v_perm_b32 in it)
-                    } else {
-                        w = __builtin_amdgcn_perm(q, q, tg.plain_sel);
-                        asm volatile("" : "+v"(w));
-                    }
+                    // (the red byte is zero where dir[0] is not positive: a select on every row.  Until the end of round 3 the
+                    // select sat behind a wave-uniform branch -- its sign rarely changes within a stretch -- but the branch and
+                    // the jump around it are scalar instructions, and the scalar unit is the busier one in this loop: 1.4 % of
+                    // the headline call)
+                    const uint32_t w = __builtin_amdgcn_perm(d0 > 0.0f ? q : 0u, q, tg.plain_sel);
                     NT_EXP_STORE_IF NT_G32(out) = w;
                     continue;
                 }
@@ -1252,7 +1251,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
             }
             while (inner != 0u) {
                 const int rr = __builtin_ctz(inner);
-                inner &= inner - 1u;
+                NT_CLEAR_BIT(inner, rr);
                 const uint32_t K = ((uint32_t)(rowcodes >> (4 * rr)) & 15u) - 1u;
                 NT_ROW_LOAD(rr);
                 float bK = bK0, uK = uK0;
@@ -1398,6 +1397,7 @@ __global__ __launch_bounds__(64 * WAVES) NT_TILE_OCC void box_tile_kernel(NtCame
 #undef NT_ROW_OFF
 #undef NT_ROW_PTR
 #undef NT_LANE_OFF
+#undef NT_CLEAR_BIT
 }
 
 template <int N>
